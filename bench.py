@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- pose-candidate NMI evaluations per second on MI355X (BASELINE.json metric).
+
+One "step" = one search over one candidate grid with the inputs already resident in HBM: the whole
+6-D grid (S renders x Wn warps) is scored by the HIP kernel, the arg-max is taken on the device and
+the 8-byte winner is read back.  N=1 runs BASELINE.json configs[1]: 640x480 frames,
+729-pose grid (27 renders x 27 warps), 256 bins.  N>1 (one process per GPU, launched by
+torch.distributed.run) shards the render axis: every rank holds its own 27 renders and the full warp
+stack (weak scaling), and the only exchange is an 8-byte MAX all-reduce of the packed winner over RCCL.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT, S_PER_RANK, WN, BINS = 640, 480, 27, 27, 256
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_eval(w, h):
+    return 2 * w * h + 4  # one u8 read of each image + one f32 score
+
+
+def cpu_baseline(wl, budget_s=12.0):
+    """The CPU oracle (a port: the reference has no CPU NMI path) on the host cores, bounded sample."""
+    from oracle import binding as oc
+    threads = min(oc.max_threads(), os.cpu_count() or 1)
+    rs, ws = wl["render_stack"], wl["warp_stack"]
+    oc.search_grid(rs[:threads], ws[:2], threads=threads, render_bottom_up=wl["bottom_up"])  # warm-up
+    evals, t0 = 0, time.perf_counter()
+    reps = 0
+    while True:
+        oc.search_grid(rs, ws, threads=threads, render_bottom_up=wl["bottom_up"])
+        evals += rs.shape[0] * ws.shape[0]
+        reps += 1
+        if time.perf_counter() - t0 >= budget_s or reps >= 50:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": evals / dt, "unit": "evals/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} x the same {rs.shape[0]}x{ws.shape[0]} grid at {WIDTH}x{HEIGHT}, {BINS} bins, "
+                      f"OpenMP over candidates, {dt:.1f} s"}
+
+
+def load_pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+
+    import orbslam2_nmi_amd as nmi
+    from orbslam2_nmi_amd import synthetic as sy
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (no CPU fallback for the NMI path)")
+    nmi.load_library()
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # ---- synthetic inputs, resident in HBM before any timing ------------------------------------------
+    # rank 0 holds the renders of the planted scene; other ranks render a different scene (their candidates score
+    # lower), so the global winner must come out of the collective as rank 0's centre cell.
+    wl = sy.workload(WIDTH, HEIGHT, S_PER_RANK, WN, seed=1234)
+    if rank > 0:
+        other = sy.scene(WIDTH, HEIGHT, 5000 + rank)
+        wl["render_stack"] = sy.render_stack(other, wl["s_counts"], bottom_up=True)
+    S_total = S_PER_RANK * world
+    s_offset = S_PER_RANK * rank
+    rs = torch.from_numpy(wl["render_stack"]).cuda()
+    ws = torch.from_numpy(wl["warp_stack"]).cuda()
+    w_c, s_c = divmod(wl["planted"], S_PER_RANK)
+    planted_global = w_c * S_total + s_c
+
+    ctx = nmi.NmiContext(WIDTH, HEIGHT, bins=BINS, max_candidates=S_PER_RANK * WN)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+    key = torch.zeros(1, dtype=torch.int64, device="cuda")
+
+    def step():
+        if world == 1:
+            return ctx.search_grid(rs, ws)
+        ctx.search_grid_shard(rs, s_offset, S_total, ws, key_out=key, blocking=False)
+        dist.all_reduce(key, op=dist.ReduceOp.MAX)  # 8 bytes over RCCL/xGMI; keys are < 2^63
+        return nmi.key_unpack(int(key.item()))
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if res[0] != planted_global:
+        sys.exit(f"rank {rank}: wrong winner {res} (expected index {planted_global})")
+
+    # ---- dominant kernel: live HIP-event timing on the launch stream ----------------------------------
+    ctx.set_profiling(True)
+    durs = []
+    for _ in range(min(args.steps, 100)):
+        if world == 1:
+            ctx.search_grid(rs, ws)
+        else:
+            ctx.search_grid_shard(rs, s_offset, S_total, ws, key_out=key, blocking=True)
+        durs.append(ctx.last_kernel_ms())
+    ctx.set_profiling(False)
+    kernel_ms = float(np.mean(durs))
+
+    if rank == 0:
+        evals_per_step = S_total * WN
+        per_launch_evals = S_PER_RANK * WN
+        achieved = per_launch_evals * algorithmic_bytes_per_eval(WIDTH, HEIGHT) / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "pose-candidate NMI evals/sec (640x480, 256 bins)",
+            "value": evals_per_step * args.steps / elapsed,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8 histogram counts (u32), f32 entropy",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: 640x480 frame, 729-pose grid (27 renders x 27 warps) per GPU, "
+                                   "256-bin NMI (SUC), render axis sharded by rank",
+                       "width": WIDTH, "height": HEIGHT, "renders_per_gpu": S_PER_RANK, "warps": WN,
+                       "candidates_total": evals_per_step, "bins": BINS,
+                       "collective": "none" if world == 1 else "8-byte MAX all-reduce (RCCL)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_pmc_traffic(),
+                         "kernel": "nmi_grid_kernel", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": per_launch_evals * algorithmic_bytes_per_eval(WIDTH, HEIGHT)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_budget)
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

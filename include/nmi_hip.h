@@ -1,0 +1,165 @@
+/*
+ * nmi_hip.h -- C ABI of libnmi_hip.so: MI355X (gfx950) implementation of the NMI pose-candidate
+ * scoring path of gsanya/orbslam2_NMI.
+ *
+ * This is the drop-in boundary.  Each entry point names the reference interface it replaces
+ * (paths relative to the reference repository root).  Plain pointers and sizes only; no C++,
+ * torch or OpenCV types.  All image pointers are DEVICE pointers unless a name starts with h_.
+ * Every function returns NMI_OK (0) or a negative error code; nothing calls exit() (the
+ * reference aborts the process through checkCudaErrors, Thirdparty/CUDA_Functions/kernel.cu:53-113).
+ *
+ * Data conventions:
+ *   image           uint8 [height][width], contiguous, row stride = width
+ *                   (cv::cuda::createContinuous CV_8UC1, Thirdparty/Localization/image.cpp:67).
+ *   render          same shape; stored bottom-up when nmi_params.render_bottom_up = 1, which is how
+ *                   the reference samples the GL texture (NMI.cu:82).
+ *   render_stack    uint8 [S][height][width],  s = (sZ*nSy + sY)*nSx + sX
+ *   warp_stack      uint8 [Wn][height][width], w = (wZ*nWy + wY)*nWx + wX
+ *   ratings         float [Wn][S]; ratings[w*S + s] == rating[wZ][wY][wX][sZ][sY][sX]
+ *                   (Thirdparty/Localization/localization.hpp:36, src/Tracking.cc:1892).
+ *   linear index    w*S + s -- the order helperFunctions::find_max_elements scans
+ *                   (Thirdparty/Localization/helperFunctions.cpp:53-64).
+ */
+#ifndef NMI_HIP_H
+#define NMI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NMI_HIP_ABI_VERSION 1
+
+/* Error codes.  HIP errors are reported as NMI_ERR_HIP - (int)hipError_t, RCCL as NMI_ERR_RCCL - (int)ncclResult_t. */
+#define NMI_OK 0
+#define NMI_ERR_INVALID_ARGUMENT (-1)
+#define NMI_ERR_UNSUPPORTED (-2)
+#define NMI_ERR_NO_DEVICE (-3)
+#define NMI_ERR_NOT_READY (-4)
+#define NMI_ERR_HIP (-1000)
+#define NMI_ERR_RCCL (-2000)
+
+/* Score selector; values follow the reference's macros ENMI 0 / SUC 1 (Thirdparty/CUDA_Functions/kernel.cuh:22-23).
+ * The reference ignores its run-time NMI_mode argument (kernel.cu:49) and compiles SUC in (NMI.cu:344,352). */
+#define NMI_MODE_ENMI 0
+#define NMI_MODE_SUC 1
+
+typedef struct nmi_ctx nmi_ctx;
+
+/*
+ * Behaviour switches that are compile-time macros in the reference, as run-time fields whose
+ * defaults (nmi_params_default) equal the reference's values.
+ */
+typedef struct nmi_params {
+    int32_t width;            /* Camera.Width  / kernel.cu:49 'width'  */
+    int32_t height;           /* Camera.Height / kernel.cu:49 'height' */
+    int32_t bins;             /* 256 = HISTOGRAM256_BIN_COUNT (NMI.cuh:39); 128/64/32/16 use intensity >> k */
+    int32_t mode;             /* NMI_MODE_SUC (kernel.cuh:23) or NMI_MODE_ENMI (kernel.cuh:22) */
+    int32_t use_bg;           /* nmi_prop_BG (Thirdparty/Localization/allProperties.hpp:38); default 1 */
+    int32_t render_bottom_up; /* 1 = vertical flip of the render as in NMI.cu:82; default 1 */
+    int32_t device;           /* HIP device ordinal; -1 = the calling thread's current device */
+    int32_t max_candidates;   /* capacity hint for the internal ratings buffer; grown on demand */
+    void *stream;             /* hipStream_t to run on; NULL = the context creates its own */
+    int32_t reserved[8];      /* must be 0 */
+} nmi_params;
+
+/* Fills *p with the reference defaults: bins 256, SUC, BG on, bottom-up render, current device. */
+int nmi_params_default(nmi_params *p, int32_t width, int32_t height);
+
+/*
+ * Persistent workspace.  Replaces the per-call allocations of CUDAF::NMIWithCuda_noMask
+ * (7 cudaMalloc kernel.cu:67-73, initHistogram256all NMI.cu:171-177, the frees at kernel.cu:103-109
+ * and closeHistogram256all NMI.cu:180-185) and the file-static buffers NMI.cu:165-167.
+ * One context = one stream; not thread-safe across threads (the reference is called from the
+ * Tracking thread only, src/Tracking.cc:1886).
+ */
+int nmi_create(const nmi_params *params, nmi_ctx **out_ctx);
+int nmi_destroy(nmi_ctx *ctx);
+
+/* Run subsequent work on this hipStream_t (not owned).  NULL restores the context's own stream. */
+int nmi_set_stream(nmi_ctx *ctx, void *stream);
+
+/*
+ * One candidate: replaces CUDAF::NMIWithCuda_noMask (Thirdparty/CUDA_Functions/kernel.cuh:37,
+ * kernel.cu:49-114) with the render given as a linear device buffer instead of a GL texture name.
+ * Blocking; *h_score receives the value the reference copies back at kernel.cu:100.
+ */
+int nmi_eval_pair(nmi_ctx *ctx, const uint8_t *render, const uint8_t *warped, float *h_score);
+
+/*
+ * Same evaluation, additionally exporting the exact integer histograms and the three entropy sums
+ * (the intermediate buffers d_JointHistogram / d_Histogram1 / d_Histogram2 and element 0 of
+ * d_Entropy1 / d_Entropy2 / d_JointEntropyShort before the score is formed, kernel.cu:59-95).
+ * Any of the device output pointers may be NULL.  joint is [256][256] indexed [render][warped].
+ */
+int nmi_eval_pair_debug(nmi_ctx *ctx, const uint8_t *render, const uint8_t *warped, float *h_score,
+                        uint32_t *d_joint /*[65536]*/, uint32_t *d_hist_render /*[256]*/,
+                        uint32_t *d_hist_warped /*[256]*/, float *d_sums /*[3]: A1, A2, A3*/);
+
+/*
+ * Whole candidate grid + best-pose pick: replaces the 6-nested loop of Tracking::RelocalizeWithNMI
+ * (src/Tracking.cc:1879-1902: S renders x Wn warps calls of NMIWithCuda_noMask) and
+ * helperFunctions::find_max_elements + the caller's [0] pick (helperFunctions.cpp:50-103,
+ * Tracking.cc:1905,1952-1953).
+ *   d_ratings       device float [Wn*S] or NULL (an internal buffer is used).
+ *   h_best_index    linear index w*S + s of the winner: max starts at 0, strict '>', lowest index
+ *                   among cells equal to the max; -1 if no cell qualifies (every score negative or
+ *                   NaN, where the reference indexes an empty vector).
+ *   h_best_score    the winner's score.
+ * Blocking (8-byte read-back of the packed winner).
+ */
+int nmi_search_grid(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S, const uint8_t *warp_stack, int32_t Wn,
+                    float *d_ratings, int64_t *h_best_index, float *h_best_score);
+
+/*
+ * Sharded form for one rank of a multi-GPU search (new; the reference is single-GPU).
+ * This rank holds renders [s_offset, s_offset + S_local) of a global grid with S_total renders and
+ * the full warp stack.  The kernel writes the rank's best candidate as a packed key to *d_key
+ * (device uint64, may be NULL to use an internal slot) and, if h_key != NULL, blocks and copies it
+ * to the host.  key = float_bits(score) << 32 | (0xFFFFFFFF - global_linear_index) for score >= 0
+ * and 0 for "no candidate"; the maximum over ranks (uint64 or int64 MAX all-reduce) is the global
+ * winner with the reference's lowest-index tie-break.  d_ratings (nullable) is [Wn][S_local].
+ * With h_key == NULL the call only enqueues work on the context's stream.
+ */
+int nmi_search_grid_shard(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S_local, int32_t s_offset,
+                          int32_t S_total, const uint8_t *warp_stack, int32_t Wn, float *d_ratings,
+                          uint64_t *d_key, uint64_t *h_key);
+
+/* Packed-key helpers (host side, pure). */
+uint64_t nmi_key_pack(float score, int64_t global_linear_index);
+int nmi_key_unpack(uint64_t key, int64_t *global_linear_index, float *score);
+
+/*
+ * RCCL form: nmi_search_grid_shard followed by ncclAllReduce(ncclMax, ncclUint64) of the key on the
+ * context's stream over `nccl_comm` (an ncclComm_t created by the caller), then the 8-byte read-back.
+ */
+int nmi_search_grid_rccl(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S_local, int32_t s_offset,
+                         int32_t S_total, const uint8_t *warp_stack, int32_t Wn, float *d_ratings,
+                         void *nccl_comm, int64_t *h_best_index, float *h_best_score);
+
+/* Communicator bootstrap for hosts that have no ncclComm_t yet: rank 0 calls nmi_rccl_unique_id and
+ * ships the 128 bytes to the other ranks by any means; every rank then calls nmi_rccl_comm_init. */
+int nmi_rccl_unique_id(uint8_t out_id[128]);
+int nmi_rccl_comm_init(nmi_ctx *ctx, const uint8_t id[128], int32_t rank, int32_t nranks, void **out_comm);
+int nmi_rccl_comm_destroy(void *nccl_comm);
+
+/*
+ * Timing of the dominant kernel with HIP events on the context's stream.  When enabled, every grid /
+ * pair launch is bracketed by hipEventRecord; nmi_last_kernel_ms returns the duration of the most
+ * recent launch (synchronises on the stop event).
+ */
+int nmi_set_profiling(nmi_ctx *ctx, int32_t enabled);
+int nmi_last_kernel_ms(nmi_ctx *ctx, float *h_ms);
+
+/* Introspection. */
+int nmi_abi_version(void);
+const char *nmi_error_string(int code);
+const char *nmi_last_error_detail(nmi_ctx *ctx); /* text of the last failing HIP/RCCL call, or "" */
+int nmi_get_info(nmi_ctx *ctx, int32_t *compute_units, int32_t *workgroups_per_launch, int32_t *lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMI_HIP_H */

@@ -1,0 +1,61 @@
+"""Builds orbslam2_nmi_amd/lib/libnmi_hip.so (gfx950) in-tree with hipcc.
+
+The shared library is the product: HIP kernels (csrc/nmi_kernels.hip) + the C ABI of include/nmi_hip.h
+(csrc/nmi_capi.cpp) + the host-side mirror of the reference's driver types (host/*.cpp).
+"""
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+LIB_DIR = os.path.join(PKG, "lib")
+LIB = os.path.join(LIB_DIR, "libnmi_hip.so")
+ARCH = "gfx950"
+
+
+def sources():
+    out = []
+    for sub in ("csrc", "host"):
+        d = os.path.join(PKG, sub)
+        if os.path.isdir(d):
+            out += [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith((".hip", ".cpp"))]
+    return out
+
+
+def headers():
+    out = [os.path.join(ROOT, "include", f) for f in sorted(os.listdir(os.path.join(ROOT, "include")))]
+    for sub in ("csrc", "host"):
+        d = os.path.join(PKG, sub)
+        if os.path.isdir(d):
+            out += [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith((".h", ".hpp"))]
+    return out
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(f) > t for f in sources() + headers() + [os.path.abspath(__file__)])
+
+
+def command():
+    return ["hipcc", "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared", "-ffp-contract=off",
+            "-Wall", "-Wno-unused-function",
+            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"), "-I" + os.path.join(PKG, "host"),
+            *sources(), "-o", LIB, "-ldl"]
+
+
+def build(force=False, verbose=False):
+    """Compile the library if sources are newer than the binary.  Returns the library path."""
+    if force or is_stale():
+        os.makedirs(LIB_DIR, exist_ok=True)
+        cmd = command()
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,282 @@
+"""ctypes view of the C ABI in include/nmi_hip.h (libnmi_hip.so).
+
+There is no CPU fallback here: if the HIP library is missing or cannot be loaded this module raises,
+and every entry point requires device (torch CUDA/HIP) tensors.  torch is used only to own device
+memory and streams; the compute is the hand-written HIP in csrc/.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+MODE_ENMI = 0  # Thirdparty/CUDA_Functions/kernel.cuh:22
+MODE_SUC = 1   # Thirdparty/CUDA_Functions/kernel.cuh:23
+
+NMI_OK = 0
+ERR_INVALID_ARGUMENT = -1
+ERR_UNSUPPORTED = -2
+ERR_NO_DEVICE = -3
+ERR_NOT_READY = -4
+
+# Every symbol include/nmi_hip.h declares; tests check that the library exports all of them.
+EXPORTED_SYMBOLS = (
+    "nmi_params_default", "nmi_create", "nmi_destroy", "nmi_set_stream", "nmi_eval_pair", "nmi_eval_pair_debug",
+    "nmi_search_grid", "nmi_search_grid_shard", "nmi_key_pack", "nmi_key_unpack", "nmi_search_grid_rccl",
+    "nmi_rccl_unique_id", "nmi_rccl_comm_init", "nmi_rccl_comm_destroy", "nmi_set_profiling", "nmi_last_kernel_ms",
+    "nmi_abi_version", "nmi_error_string", "nmi_last_error_detail", "nmi_get_info",
+)
+
+
+class NmiParams(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32), ("bins", C.c_int32), ("mode", C.c_int32),
+        ("use_bg", C.c_int32), ("render_bottom_up", C.c_int32), ("device", C.c_int32),
+        ("max_candidates", C.c_int32), ("stream", C.c_void_p), ("reserved", C.c_int32 * 8),
+    ]
+
+
+class NmiError(RuntimeError):
+    def __init__(self, code, what, detail=""):
+        self.code = code
+        super().__init__(f"{what} failed: {code} ({error_string(code)}) {detail}".strip())
+
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def load_library(build_if_missing=False):
+    """Loads libnmi_hip.so.  Raises if it is not there (the product has no other compute path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if build_if_missing:
+        _build.build()
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run `python -m orbslam2_nmi_amd.build` (hipcc, gfx950). "
+                           "There is no CPU fallback for the NMI path.")
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    vp, i32, i64p, f32p, u64p = C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_uint64)
+    lib.nmi_params_default.argtypes = [C.POINTER(NmiParams), i32, i32]
+    lib.nmi_create.argtypes = [C.POINTER(NmiParams), C.POINTER(vp)]
+    lib.nmi_destroy.argtypes = [vp]
+    lib.nmi_set_stream.argtypes = [vp, vp]
+    lib.nmi_eval_pair.argtypes = [vp, vp, vp, f32p]
+    lib.nmi_eval_pair_debug.argtypes = [vp, vp, vp, f32p, vp, vp, vp, vp]
+    lib.nmi_search_grid.argtypes = [vp, vp, i32, vp, i32, vp, i64p, f32p]
+    lib.nmi_search_grid_shard.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp, u64p]
+    lib.nmi_key_pack.argtypes = [C.c_float, C.c_int64]
+    lib.nmi_key_pack.restype = C.c_uint64
+    lib.nmi_key_unpack.argtypes = [C.c_uint64, i64p, f32p]
+    lib.nmi_search_grid_rccl.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp, i64p, f32p]
+    lib.nmi_rccl_unique_id.argtypes = [C.POINTER(C.c_uint8)]
+    lib.nmi_rccl_comm_init.argtypes = [vp, C.POINTER(C.c_uint8), i32, i32, C.POINTER(vp)]
+    lib.nmi_rccl_comm_destroy.argtypes = [vp]
+    lib.nmi_set_profiling.argtypes = [vp, i32]
+    lib.nmi_last_kernel_ms.argtypes = [vp, f32p]
+    lib.nmi_error_string.argtypes = [C.c_int]
+    lib.nmi_error_string.restype = C.c_char_p
+    lib.nmi_last_error_detail.argtypes = [vp]
+    lib.nmi_last_error_detail.restype = C.c_char_p
+    lib.nmi_get_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    _lib = lib
+    return lib
+
+
+def error_string(code):
+    return load_library().nmi_error_string(int(code)).decode()
+
+
+def key_pack(score, index):
+    return int(load_library().nmi_key_pack(float(score), int(index)))
+
+
+def key_unpack(key):
+    idx, sc = C.c_int64(0), C.c_float(0)
+    load_library().nmi_key_unpack(C.c_uint64(int(key) & 0xFFFFFFFFFFFFFFFF), C.byref(idx), C.byref(sc))
+    return int(idx.value), np.float32(sc.value)
+
+
+def _dev_u8(t, ndim, what):
+    import torch
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError(f"{what} must be a device (HIP) torch tensor; the NMI path has no CPU implementation")
+    if t.dtype != torch.uint8 or t.dim() != ndim or not t.is_contiguous():
+        raise TypeError(f"{what} must be a contiguous uint8 tensor with {ndim} dims, got {t.dtype} {tuple(t.shape)}")
+    return t
+
+
+class NmiContext:
+    """nmi_ctx wrapper.  Mirrors the per-search objects of the reference (NmiObjects' buffers +
+    the CUDA scratch of kernel.cu:59-73) as one persistent workspace."""
+
+    def __init__(self, width, height, bins=256, mode=MODE_SUC, use_bg=True, render_bottom_up=True, device=None,
+                 stream=None, max_candidates=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: orbslam2_nmi_amd needs an AMD GPU (gfx950)")
+        self._lib = load_library()
+        self.width, self.height = int(width), int(height)
+        self.bins, self.mode, self.use_bg, self.render_bottom_up = bins, mode, bool(use_bg), bool(render_bottom_up)
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", int(device) if not isinstance(device, torch.device) else device.index or 0)
+        p = NmiParams()
+        self._check(self._lib.nmi_params_default(C.byref(p), self.width, self.height), "nmi_params_default")
+        p.bins, p.mode, p.use_bg, p.render_bottom_up = int(bins), int(mode), int(bool(use_bg)), int(bool(render_bottom_up))
+        p.device = self.device.index
+        p.max_candidates = int(max_candidates)
+        p.stream = stream
+        self._h = C.c_void_p()
+        rc = self._lib.nmi_create(C.byref(p), C.byref(self._h))
+        if rc != NMI_OK:
+            self._h = C.c_void_p()
+            raise NmiError(rc, "nmi_create")
+
+    # -- plumbing -------------------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != NMI_OK:
+            detail = self._lib.nmi_last_error_detail(self._h).decode() if getattr(self, "_h", None) else ""
+            raise NmiError(rc, what, detail)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.nmi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_stream(self, stream_handle):
+        """Run on this hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); None = own stream."""
+        self._check(self._lib.nmi_set_stream(self._h, C.c_void_p(stream_handle)), "nmi_set_stream")
+
+    def set_profiling(self, on):
+        self._check(self._lib.nmi_set_profiling(self._h, int(bool(on))), "nmi_set_profiling")
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        self._check(self._lib.nmi_last_kernel_ms(self._h, C.byref(ms)), "nmi_last_kernel_ms")
+        return float(ms.value)
+
+    def info(self):
+        cu, wg, lds = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.nmi_get_info(self._h, C.byref(cu), C.byref(wg), C.byref(lds)), "nmi_get_info")
+        return {"compute_units": cu.value, "workgroups_per_launch": wg.value, "lds_bytes": lds.value}
+
+    def _img(self, t, what):
+        t = _dev_u8(t, 2, what)
+        if tuple(t.shape) != (self.height, self.width):
+            raise ValueError(f"{what} is {tuple(t.shape)}, context is {(self.height, self.width)}")
+        return t
+
+    def _stack(self, t, what):
+        t = _dev_u8(t, 3, what)
+        if tuple(t.shape[1:]) != (self.height, self.width):
+            raise ValueError(f"{what} is {tuple(t.shape)}, context images are {(self.height, self.width)}")
+        return t
+
+    # -- the path -------------------------------------------------------------------------------
+    def eval_pair(self, render, warped):
+        """CUDAF::NMIWithCuda_noMask (kernel.cu:49-114) for one (render, warped frame) pair -> float32 score."""
+        r, w = self._img(render, "render"), self._img(warped, "warped")
+        out = C.c_float(0)
+        self._check(self._lib.nmi_eval_pair(self._h, r.data_ptr(), w.data_ptr(), C.byref(out)), "nmi_eval_pair")
+        return np.float32(out.value)
+
+    def eval_pair_debug(self, render, warped):
+        """-> (score, joint[256,256] u32 (render x warped), hist_render[256], hist_warped[256], sums[3]) as numpy."""
+        import torch
+        r, w = self._img(render, "render"), self._img(warped, "warped")
+        joint = torch.zeros(65536, dtype=torch.int32, device=self.device)
+        h1 = torch.zeros(256, dtype=torch.int32, device=self.device)
+        h2 = torch.zeros(256, dtype=torch.int32, device=self.device)
+        sums = torch.zeros(3, dtype=torch.float32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        out = C.c_float(0)
+        self._check(self._lib.nmi_eval_pair_debug(self._h, r.data_ptr(), w.data_ptr(), C.byref(out), joint.data_ptr(),
+                                                  h1.data_ptr(), h2.data_ptr(), sums.data_ptr()), "nmi_eval_pair_debug")
+        u32 = lambda t: t.cpu().numpy().view(np.uint32)
+        return np.float32(out.value), u32(joint).reshape(256, 256), u32(h1), u32(h2), sums.cpu().numpy()
+
+    def search_grid(self, render_stack, warp_stack, ratings=None):
+        """Candidate loop + arg-max (Tracking.cc:1879-1905,1952).  -> (best linear index w*S+s, best score).
+
+        ratings: optional device float32 tensor [Wn, S] that receives the full rating table."""
+        rs, ws = self._stack(render_stack, "render_stack"), self._stack(warp_stack, "warp_stack")
+        S, Wn = rs.shape[0], ws.shape[0]
+        rp = self._ratings_ptr(ratings, Wn, S)
+        idx, sc = C.c_int64(0), C.c_float(0)
+        self._check(self._lib.nmi_search_grid(self._h, rs.data_ptr(), S, ws.data_ptr(), Wn, rp, C.byref(idx), C.byref(sc)),
+                    "nmi_search_grid")
+        return int(idx.value), np.float32(sc.value)
+
+    def search_grid_shard(self, render_stack, s_offset, s_total, warp_stack, ratings=None, key_out=None, blocking=True):
+        """One rank's part of a sharded search.  -> packed key (int) if blocking else None.
+
+        key_out: optional device int64/uint64 tensor of one element that receives the key (for a collective)."""
+        rs, ws = self._stack(render_stack, "render_stack"), self._stack(warp_stack, "warp_stack")
+        S, Wn = rs.shape[0], ws.shape[0]
+        rp = self._ratings_ptr(ratings, Wn, S)
+        kp = None
+        if key_out is not None:
+            if not key_out.is_cuda or key_out.numel() != 1 or key_out.element_size() != 8:
+                raise TypeError("key_out must be a one-element 64-bit device tensor")
+            kp = key_out.data_ptr()
+        hk = C.c_uint64(0)
+        self._check(self._lib.nmi_search_grid_shard(self._h, rs.data_ptr(), S, int(s_offset), int(s_total), ws.data_ptr(),
+                                                    Wn, rp, kp, C.byref(hk) if blocking else None),
+                    "nmi_search_grid_shard")
+        return int(hk.value) if blocking else None
+
+    def _ratings_ptr(self, ratings, Wn, S):
+        import torch
+        if ratings is None:
+            return None
+        if (not ratings.is_cuda or ratings.dtype != torch.float32 or not ratings.is_contiguous()
+                or ratings.numel() != Wn * S):
+            raise TypeError(f"ratings must be a contiguous float32 device tensor with {Wn * S} elements")
+        return ratings.data_ptr()
+
+    # -- RCCL -----------------------------------------------------------------------------------
+    def rccl_comm_init(self, unique_id: bytes, rank, nranks):
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        comm = C.c_void_p()
+        self._check(self._lib.nmi_rccl_comm_init(self._h, buf, rank, nranks, C.byref(comm)), "nmi_rccl_comm_init")
+        return comm
+
+    def search_grid_rccl(self, render_stack, s_offset, s_total, warp_stack, comm, ratings=None):
+        rs, ws = self._stack(render_stack, "render_stack"), self._stack(warp_stack, "warp_stack")
+        S, Wn = rs.shape[0], ws.shape[0]
+        idx, sc = C.c_int64(0), C.c_float(0)
+        self._check(self._lib.nmi_search_grid_rccl(self._h, rs.data_ptr(), S, int(s_offset), int(s_total), ws.data_ptr(),
+                                                   Wn, self._ratings_ptr(ratings, Wn, S), comm, C.byref(idx),
+                                                   C.byref(sc)), "nmi_search_grid_rccl")
+        return int(idx.value), np.float32(sc.value)
+
+
+def rccl_unique_id():
+    buf = (C.c_uint8 * 128)()
+    rc = load_library().nmi_rccl_unique_id(buf)
+    if rc != NMI_OK:
+        raise NmiError(rc, "nmi_rccl_unique_id")
+    return bytes(buf)
+
+
+def rccl_comm_destroy(comm):
+    load_library().nmi_rccl_comm_destroy(comm)

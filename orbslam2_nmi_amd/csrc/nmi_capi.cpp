@@ -1,0 +1,467 @@
+// nmi_capi.cpp -- the C ABI declared in include/nmi_hip.h on top of the gfx950 kernels.
+//
+// Host orchestration that replaces CUDAF::NMIWithCuda_noMask (Thirdparty/CUDA_Functions/kernel.cu:49-114)
+// and the candidate loop + arg-max of Tracking::RelocalizeWithNMI (src/Tracking.cc:1879-1905,1952):
+// a persistent context owns every buffer, one launch scores a whole candidate grid, and the only
+// host<->device traffic per search is one 8-byte key.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+
+#include "nmi_hip.h"
+#include "nmi_kernels.h"
+
+struct nmi_ctx {
+    nmi_params params{};
+    int device = 0;
+    int compute_units = 0;
+    int npix = 0;
+    int shift = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    float *table = nullptr;             // [npix + 1]
+    float *ratings = nullptr;           // internal rating table
+    int64_t ratings_cap = 0;
+    unsigned long long *d_key = nullptr;  // device slot for the packed winner
+    unsigned long long *h_key = nullptr;  // pinned host mirror
+    float *d_pair_rating = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool profiling = false;
+    bool have_timing = false;
+    std::string detail;
+};
+
+namespace {
+
+int hip_fail(nmi_ctx *ctx, hipError_t e, const char *what)
+{
+    if (ctx) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+        ctx->detail = buf;
+    }
+    return NMI_ERR_HIP - (int)e;
+}
+
+#define NMI_HIP_TRY(ctx, call)                                  \
+    do {                                                        \
+        hipError_t e_ = (call);                                 \
+        if (e_ != hipSuccess) return hip_fail((ctx), e_, #call); \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool active = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) active = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (active) (void)hipSetDevice(prev);
+    }
+};
+
+int ensure_ratings(nmi_ctx *ctx, int64_t n)
+{
+    if (n <= ctx->ratings_cap) return NMI_OK;
+    if (ctx->ratings) NMI_HIP_TRY(ctx, hipFree(ctx->ratings));
+    ctx->ratings = nullptr;
+    ctx->ratings_cap = 0;
+    NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->ratings, (size_t)n * sizeof(float)));
+    ctx->ratings_cap = n;
+    return NMI_OK;
+}
+
+// Enqueues: key reset, the grid kernel.  No synchronisation.
+int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_offset, int S_total,
+                 const uint8_t *warp_stack, int Wn, float *d_ratings, unsigned long long *d_key, uint32_t *dbg_joint,
+                 uint32_t *dbg_h1, uint32_t *dbg_h2, float *dbg_sums)
+{
+    const nmi_params &p = ctx->params;
+    nmi::GridArgs a{};
+    a.render_stack = render_stack;
+    a.warp_stack = warp_stack;
+    a.S_local = S_local;
+    a.Wn = Wn;
+    a.s_offset = s_offset;
+    a.S_total = S_total;
+    a.width = p.width;
+    a.height = p.height;
+    a.npix = ctx->npix;
+    a.vec_ok = (p.width % 16 == 0) && (((uintptr_t)render_stack | (uintptr_t)warp_stack) % 16 == 0);
+    a.chunks_per_row = a.vec_ok ? p.width / 16 : 1;
+    a.cpr_magic = a.chunks_per_row > 1 ? (uint32_t)((0x100000000ull + a.chunks_per_row - 1) / a.chunks_per_row) : 0u;
+    a.shift = ctx->shift;
+    a.mode = p.mode;
+    a.flip = p.render_bottom_up ? 1 : 0;
+    a.table = ctx->table;
+    a.ratings = d_ratings;
+    a.key = d_key;
+    a.dbg_joint = dbg_joint;
+    a.dbg_h1 = dbg_h1;
+    a.dbg_h2 = dbg_h2;
+    a.dbg_sums = dbg_sums;
+
+    NMI_HIP_TRY(ctx, hipMemsetAsync(d_key, 0, sizeof(unsigned long long), ctx->stream));
+    const int64_t total = (int64_t)S_local * Wn;
+    if (total == 0) return NMI_OK;
+    const int workgroups = (int)(total < ctx->compute_units ? total : ctx->compute_units);
+    if (ctx->profiling) NMI_HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    NMI_HIP_TRY(ctx, nmi::launch_grid(a, workgroups, p.use_bg != 0, ctx->stream));
+    if (ctx->profiling) {
+        NMI_HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+        ctx->have_timing = true;
+    }
+    return NMI_OK;
+}
+
+int check_grid_args(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_offset, int S_total,
+                    const uint8_t *warp_stack, int Wn)
+{
+    if (!ctx) return NMI_ERR_INVALID_ARGUMENT;
+    ctx->detail.clear();
+    if (S_local < 0 || Wn < 0 || s_offset < 0 || S_total < S_local || s_offset + S_local > S_total)
+        return NMI_ERR_INVALID_ARGUMENT;
+    if ((S_local > 0 && !render_stack) || (Wn > 0 && !warp_stack)) return NMI_ERR_INVALID_ARGUMENT;
+    if ((int64_t)S_total * Wn >= 0x7FFFFFFFll) return NMI_ERR_UNSUPPORTED;  // index lives in 32 bits of the key
+    return NMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nmi_abi_version(void) { return NMI_HIP_ABI_VERSION; }
+
+const char *nmi_error_string(int code)
+{
+    if (code == NMI_OK) return "ok";
+    if (code == NMI_ERR_INVALID_ARGUMENT) return "invalid argument";
+    if (code == NMI_ERR_UNSUPPORTED) return "unsupported configuration";
+    if (code == NMI_ERR_NO_DEVICE) return "no usable HIP device";
+    if (code == NMI_ERR_NOT_READY) return "not ready";
+    if (code <= NMI_ERR_RCCL) return "RCCL error";
+    if (code <= NMI_ERR_HIP) return hipGetErrorString((hipError_t)(NMI_ERR_HIP - code));
+    return "unknown error";
+}
+
+const char *nmi_last_error_detail(nmi_ctx *ctx) { return ctx ? ctx->detail.c_str() : ""; }
+
+int nmi_params_default(nmi_params *p, int32_t width, int32_t height)
+{
+    if (!p) return NMI_ERR_INVALID_ARGUMENT;
+    memset(p, 0, sizeof *p);
+    p->width = width;
+    p->height = height;
+    p->bins = 256;             // HISTOGRAM256_BIN_COUNT, NMI.cuh:39
+    p->mode = NMI_MODE_SUC;    // kernel.cuh:22-23 + NMI.cu:344,352
+    p->use_bg = 1;             // nmi_prop_BG true, allProperties.hpp:38
+    p->render_bottom_up = 1;   // NMI.cu:82
+    p->device = -1;
+    p->max_candidates = 0;
+    p->stream = nullptr;
+    return NMI_OK;
+}
+
+int nmi_create(const nmi_params *params, nmi_ctx **out_ctx)
+{
+    if (!params || !out_ctx) return NMI_ERR_INVALID_ARGUMENT;
+    *out_ctx = nullptr;
+    const nmi_params &p = *params;
+    if (p.width <= 0 || p.height <= 0) return NMI_ERR_INVALID_ARGUMENT;
+    if ((int64_t)p.width * p.height > (1ll << 24)) return NMI_ERR_UNSUPPORTED;  // counts must stay exact in fp32
+    if (p.mode != NMI_MODE_SUC && p.mode != NMI_MODE_ENMI) return NMI_ERR_INVALID_ARGUMENT;
+    int shift = -1;
+    for (int k = 0; k <= 4; ++k)
+        if (p.bins == (256 >> k)) shift = k;
+    if (shift < 0) return NMI_ERR_UNSUPPORTED;
+    for (int r : p.reserved)
+        if (r != 0) return NMI_ERR_INVALID_ARGUMENT;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return NMI_ERR_NO_DEVICE;
+    int dev = p.device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return NMI_ERR_NO_DEVICE;
+    if (dev >= ndev) return NMI_ERR_INVALID_ARGUMENT;
+
+    nmi_ctx *ctx = new (std::nothrow) nmi_ctx;
+    if (!ctx) return NMI_ERR_INVALID_ARGUMENT;
+    ctx->params = p;
+    ctx->device = dev;
+    ctx->npix = p.width * p.height;
+    ctx->shift = shift;
+    DeviceGuard guard(dev);
+
+    int rc = NMI_OK;
+    auto fail = [&](hipError_t e, const char *what) {
+        rc = hip_fail(ctx, e, what);
+        fprintf(stderr, "nmi_create: %s\n", ctx->detail.c_str());
+        nmi_destroy(ctx);
+        return rc;
+    };
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return fail(e, "hipGetDeviceProperties");
+    ctx->compute_units = prop.multiProcessorCount;
+    if ((size_t)nmi::grid_kernel_lds_bytes() > prop.sharedMemPerBlock) {
+        // The kernel keeps a whole packed joint histogram in LDS: it needs a CU with >= 136 KiB (gfx950: 160 KiB).
+        nmi_destroy(ctx);
+        return NMI_ERR_UNSUPPORTED;
+    }
+    if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess)
+        return fail(e, "hipStreamCreateWithFlags");
+    ctx->stream = p.stream ? (hipStream_t)p.stream : ctx->own_stream;
+    if ((e = hipMalloc((void **)&ctx->table, ((size_t)ctx->npix + 1) * sizeof(float))) != hipSuccess)
+        return fail(e, "hipMalloc(table)");
+    if ((e = hipMalloc((void **)&ctx->d_key, sizeof(unsigned long long))) != hipSuccess) return fail(e, "hipMalloc(key)");
+    if ((e = hipMalloc((void **)&ctx->d_pair_rating, sizeof(float))) != hipSuccess) return fail(e, "hipMalloc(rating)");
+    if ((e = hipHostMalloc((void **)&ctx->h_key, sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
+        return fail(e, "hipHostMalloc(key)");
+    if ((e = hipEventCreate(&ctx->ev_start)) != hipSuccess) return fail(e, "hipEventCreate");
+    if ((e = hipEventCreate(&ctx->ev_stop)) != hipSuccess) return fail(e, "hipEventCreate");
+    if ((e = nmi::launch_table(ctx->table, ctx->npix, ctx->stream)) != hipSuccess) return fail(e, "launch_table");
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");
+    if (p.max_candidates > 0 && (rc = ensure_ratings(ctx, p.max_candidates)) != NMI_OK) {
+        nmi_destroy(ctx);
+        return rc;
+    }
+    *out_ctx = ctx;
+    return NMI_OK;
+}
+
+int nmi_destroy(nmi_ctx *ctx)
+{
+    if (!ctx) return NMI_OK;
+    DeviceGuard guard(ctx->device);
+    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    if (ctx->table) (void)hipFree(ctx->table);
+    if (ctx->ratings) (void)hipFree(ctx->ratings);
+    if (ctx->d_key) (void)hipFree(ctx->d_key);
+    if (ctx->d_pair_rating) (void)hipFree(ctx->d_pair_rating);
+    if (ctx->h_key) (void)hipHostFree(ctx->h_key);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return NMI_OK;
+}
+
+int nmi_set_stream(nmi_ctx *ctx, void *stream)
+{
+    if (!ctx) return NMI_ERR_INVALID_ARGUMENT;
+    ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    return NMI_OK;
+}
+
+int nmi_set_profiling(nmi_ctx *ctx, int32_t enabled)
+{
+    if (!ctx) return NMI_ERR_INVALID_ARGUMENT;
+    ctx->profiling = enabled != 0;
+    ctx->have_timing = false;
+    return NMI_OK;
+}
+
+int nmi_last_kernel_ms(nmi_ctx *ctx, float *h_ms)
+{
+    if (!ctx || !h_ms) return NMI_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_timing) return NMI_ERR_NOT_READY;
+    DeviceGuard guard(ctx->device);
+    NMI_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
+    NMI_HIP_TRY(ctx, hipEventElapsedTime(h_ms, ctx->ev_start, ctx->ev_stop));
+    return NMI_OK;
+}
+
+int nmi_get_info(nmi_ctx *ctx, int32_t *compute_units, int32_t *workgroups_per_launch, int32_t *lds_bytes)
+{
+    if (!ctx) return NMI_ERR_INVALID_ARGUMENT;
+    if (compute_units) *compute_units = ctx->compute_units;
+    if (workgroups_per_launch) *workgroups_per_launch = ctx->compute_units;
+    if (lds_bytes) *lds_bytes = nmi::grid_kernel_lds_bytes();
+    return NMI_OK;
+}
+
+uint64_t nmi_key_pack(float score, int64_t global_linear_index)
+{
+    if (!(score >= 0.0f) || global_linear_index < 0 || global_linear_index >= 0xFFFFFFFFll) return 0;
+    uint32_t bits = 0;
+    if (score != 0.0f) memcpy(&bits, &score, sizeof bits);
+    return ((uint64_t)bits << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)global_linear_index);
+}
+
+int nmi_key_unpack(uint64_t key, int64_t *global_linear_index, float *score)
+{
+    if (key == 0) {
+        if (global_linear_index) *global_linear_index = -1;
+        if (score) *score = 0.0f;
+        return NMI_OK;
+    }
+    const uint32_t bits = (uint32_t)(key >> 32);
+    if (global_linear_index) *global_linear_index = (int64_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu));
+    if (score) memcpy(score, &bits, sizeof bits);
+    return NMI_OK;
+}
+
+int nmi_search_grid_shard(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S_local, int32_t s_offset, int32_t S_total,
+                          const uint8_t *warp_stack, int32_t Wn, float *d_ratings, uint64_t *d_key, uint64_t *h_key)
+{
+    int rc = check_grid_args(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn);
+    if (rc != NMI_OK) return rc;
+    DeviceGuard guard(ctx->device);
+    unsigned long long *key = d_key ? (unsigned long long *)d_key : ctx->d_key;
+    rc = enqueue_grid(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn, d_ratings, key, nullptr, nullptr,
+                      nullptr, nullptr);
+    if (rc != NMI_OK) return rc;
+    if (h_key) {
+        NMI_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_key, key, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        *h_key = *ctx->h_key;
+    }
+    return NMI_OK;
+}
+
+int nmi_search_grid(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S, const uint8_t *warp_stack, int32_t Wn,
+                    float *d_ratings, int64_t *h_best_index, float *h_best_score)
+{
+    uint64_t key = 0;
+    int rc = nmi_search_grid_shard(ctx, render_stack, S, 0, S, warp_stack, Wn, d_ratings, nullptr, &key);
+    if (rc != NMI_OK) return rc;
+    return nmi_key_unpack(key, h_best_index, h_best_score);
+}
+
+int nmi_eval_pair_debug(nmi_ctx *ctx, const uint8_t *render, const uint8_t *warped, float *h_score, uint32_t *d_joint,
+                        uint32_t *d_hist_render, uint32_t *d_hist_warped, float *d_sums)
+{
+    if (!ctx || !render || !warped || !h_score) return NMI_ERR_INVALID_ARGUMENT;
+    ctx->detail.clear();
+    DeviceGuard guard(ctx->device);
+    int rc = enqueue_grid(ctx, render, 1, 0, 1, warped, 1, ctx->d_pair_rating, ctx->d_key, d_joint, d_hist_render,
+                          d_hist_warped, d_sums);
+    if (rc != NMI_OK) return rc;
+    // kernel.cu:100: the blocking 4-byte copy of the score back to the caller.
+    NMI_HIP_TRY(ctx, hipMemcpyAsync(h_score, ctx->d_pair_rating, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return NMI_OK;
+}
+
+int nmi_eval_pair(nmi_ctx *ctx, const uint8_t *render, const uint8_t *warped, float *h_score)
+{
+    return nmi_eval_pair_debug(ctx, render, warped, h_score, nullptr, nullptr, nullptr, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// RCCL (resolved at run time so that single-GPU users never load librccl).
+// ---------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+struct NcclUniqueId128 {
+    char internal[128];
+};
+typedef int (*fn_get_unique_id)(NcclUniqueId128 *);
+typedef int (*fn_comm_init_rank)(void **, int, NcclUniqueId128, int);
+typedef int (*fn_comm_destroy)(void *);
+typedef int (*fn_all_reduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef const char *(*fn_error_string)(int);
+
+struct Rccl {
+    void *handle = nullptr;
+    fn_get_unique_id get_unique_id = nullptr;
+    fn_comm_init_rank comm_init_rank = nullptr;
+    fn_comm_destroy comm_destroy = nullptr;
+    fn_all_reduce all_reduce = nullptr;
+    fn_error_string error_string = nullptr;
+    bool ok = false;
+};
+
+// ncclDataType_t / ncclRedOp_t values of rccl.h (ncclUint64 = 5, ncclMax = 2).
+constexpr int kNcclUint64 = 5;
+constexpr int kNcclMax = 2;
+
+Rccl &rccl()
+{
+    static Rccl r = [] {
+        Rccl x;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names)
+            if ((x.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!x.handle) return x;
+        x.get_unique_id = (fn_get_unique_id)dlsym(x.handle, "ncclGetUniqueId");
+        x.comm_init_rank = (fn_comm_init_rank)dlsym(x.handle, "ncclCommInitRank");
+        x.comm_destroy = (fn_comm_destroy)dlsym(x.handle, "ncclCommDestroy");
+        x.all_reduce = (fn_all_reduce)dlsym(x.handle, "ncclAllReduce");
+        x.error_string = (fn_error_string)dlsym(x.handle, "ncclGetErrorString");
+        x.ok = x.get_unique_id && x.comm_init_rank && x.comm_destroy && x.all_reduce;
+        return x;
+    }();
+    return r;
+}
+
+int rccl_fail(nmi_ctx *ctx, int r, const char *what)
+{
+    if (ctx) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "%s: %s (%d)", what, rccl().error_string ? rccl().error_string(r) : "rccl", r);
+        ctx->detail = buf;
+    }
+    return NMI_ERR_RCCL - r;
+}
+}  // namespace
+
+extern "C" {
+
+int nmi_rccl_unique_id(uint8_t out_id[128])
+{
+    if (!out_id) return NMI_ERR_INVALID_ARGUMENT;
+    if (!rccl().ok) return NMI_ERR_UNSUPPORTED;
+    NcclUniqueId128 id;
+    int r = rccl().get_unique_id(&id);
+    if (r != 0) return rccl_fail(nullptr, r, "ncclGetUniqueId");
+    memcpy(out_id, id.internal, 128);
+    return NMI_OK;
+}
+
+int nmi_rccl_comm_init(nmi_ctx *ctx, const uint8_t id[128], int32_t rank, int32_t nranks, void **out_comm)
+{
+    if (!ctx || !id || !out_comm || nranks <= 0 || rank < 0 || rank >= nranks) return NMI_ERR_INVALID_ARGUMENT;
+    if (!rccl().ok) return NMI_ERR_UNSUPPORTED;
+    DeviceGuard guard(ctx->device);
+    NcclUniqueId128 uid;
+    memcpy(uid.internal, id, 128);
+    void *comm = nullptr;
+    int r = rccl().comm_init_rank(&comm, nranks, uid, rank);
+    if (r != 0) return rccl_fail(ctx, r, "ncclCommInitRank");
+    *out_comm = comm;
+    return NMI_OK;
+}
+
+int nmi_rccl_comm_destroy(void *nccl_comm)
+{
+    if (!nccl_comm) return NMI_OK;
+    if (!rccl().ok) return NMI_ERR_UNSUPPORTED;
+    int r = rccl().comm_destroy(nccl_comm);
+    return r == 0 ? NMI_OK : NMI_ERR_RCCL - r;
+}
+
+int nmi_search_grid_rccl(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S_local, int32_t s_offset, int32_t S_total,
+                         const uint8_t *warp_stack, int32_t Wn, float *d_ratings, void *nccl_comm, int64_t *h_best_index,
+                         float *h_best_score)
+{
+    if (!nccl_comm) return NMI_ERR_INVALID_ARGUMENT;
+    if (!rccl().ok) return NMI_ERR_UNSUPPORTED;
+    int rc = nmi_search_grid_shard(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn, d_ratings, nullptr, nullptr);
+    if (rc != NMI_OK) return rc;
+    DeviceGuard guard(ctx->device);
+    // The only exchange of the search: 8 bytes per rank, max over ranks.
+    int r = rccl().all_reduce(ctx->d_key, ctx->d_key, 1, kNcclUint64, kNcclMax, nccl_comm, ctx->stream);
+    if (r != 0) return rccl_fail(ctx, r, "ncclAllReduce");
+    NMI_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_key, ctx->d_key, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return nmi_key_unpack(*ctx->h_key, h_best_index, h_best_score);
+}
+
+}  // extern "C"

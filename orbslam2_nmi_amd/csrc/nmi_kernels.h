@@ -1,0 +1,35 @@
+// nmi_kernels.h -- internal interface between the C ABI (nmi_capi.cpp) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NMI_BLOCK_THREADS 1024
+#define NMI_MODE_ENMI_ 0  // Thirdparty/CUDA_Functions/kernel.cuh:22
+#define NMI_MODE_SUC_ 1   // Thirdparty/CUDA_Functions/kernel.cuh:23
+
+namespace nmi {
+
+struct GridArgs {
+    const uint8_t *render_stack;  // [S_local][H][W]
+    const uint8_t *warp_stack;    // [Wn][H][W]
+    int S_local, Wn;
+    int s_offset, S_total;        // position of this shard in the global grid
+    int width, height, npix;
+    int chunks_per_row;           // width / 16 when vec_ok
+    uint32_t cpr_magic;           // ceil(2^32 / chunks_per_row)
+    int vec_ok;                   // width % 16 == 0 and both stacks 16-byte aligned
+    int shift;                    // intensity >> shift (bins = 256 >> shift)
+    int mode;                     // NMI_MODE_*_
+    int flip;                     // render stored bottom-up (NMI.cu:82)
+    const float *table;           // [npix + 1] per-count entropy terms
+    float *ratings;               // [Wn][S_local] or nullptr
+    unsigned long long *key;      // packed arg-max slot
+    uint32_t *dbg_joint, *dbg_h1, *dbg_h2;
+    float *dbg_sums;
+};
+
+hipError_t launch_table(float *table, int npix, hipStream_t stream);
+hipError_t launch_grid(const GridArgs &a, int workgroups, bool use_bg, hipStream_t stream);
+int grid_kernel_lds_bytes();
+
+}  // namespace nmi

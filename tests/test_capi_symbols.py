@@ -1,0 +1,88 @@
+"""CPU checks of the drop-in boundary: libnmi_hip.so loads, exports every symbol include/nmi_hip.h declares, and
+its pure host helpers (key packing) behave.  No compute call is made here (no GPU in this tier)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from orbslam2_nmi_amd import build as nmi_build
+from orbslam2_nmi_amd import capi
+
+
+@pytest.fixture(scope="module")
+def lib():
+    nmi_build.build()
+    return capi.load_library()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "nmi_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nmi_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == sorted(capi.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    raw = C.CDLL(capi.library_path())
+    for name in declared_symbols():
+        assert hasattr(raw, name), f"libnmi_hip.so does not export {name}"
+    assert lib.nmi_abi_version() == 1
+
+
+def test_params_default_match_reference_macros(lib):
+    p = capi.NmiParams()
+    assert lib.nmi_params_default(C.byref(p), 640, 480) == 0
+    assert (p.width, p.height) == (640, 480)
+    assert p.bins == 256            # NMI.cuh:39
+    assert p.mode == capi.MODE_SUC  # kernel.cuh:23, NMI.cu:352
+    assert p.use_bg == 1            # allProperties.hpp:38
+    assert p.render_bottom_up == 1  # NMI.cu:82
+    assert p.device == -1 and p.stream is None
+
+
+def test_key_pack_orders_like_find_max(lib):
+    f32 = np.float32
+    # larger score wins; equal scores -> lower index wins (max of the key)
+    assert capi.key_pack(0.5, 10) > capi.key_pack(0.25, 0)
+    assert capi.key_pack(0.5, 3) > capi.key_pack(0.5, 4)
+    # zero scores are candidates (first exact zero wins when nothing is positive); negatives / NaN are not
+    assert capi.key_pack(0.0, 7) > 0 and capi.key_pack(-0.0, 7) == capi.key_pack(0.0, 7)
+    assert capi.key_pack(-1e-9, 0) == 0 and capi.key_pack(float("nan"), 0) == 0
+    assert capi.key_unpack(0) == (-1, f32(0))
+    for s, i in ((0.123456, 0), (1.0, 728), (2.0, 32767), (0.0, 5)):
+        assert capi.key_unpack(capi.key_pack(s, i)) == (i, f32(s))
+    # monotone in the score for non-negative floats, and fits a signed 64-bit MAX all-reduce
+    xs = np.sort(np.abs(np.random.default_rng(0).standard_normal(200)).astype(f32))
+    ks = [capi.key_pack(float(x), 1) for x in xs]
+    assert ks == sorted(ks) and all(k < 2 ** 63 for k in ks)
+
+
+def test_error_strings(lib):
+    assert capi.error_string(0) == "ok"
+    assert "invalid" in capi.error_string(capi.ERR_INVALID_ARGUMENT)
+    assert capi.error_string(-1000 - 2) != ""  # hipErrorOutOfMemory text
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        capi.NmiContext(64, 48)
+    # argument validation that needs no device
+    p = capi.NmiParams()
+    l = capi.load_library()
+    l.nmi_params_default(C.byref(p), 0, 48)
+    h = C.c_void_p()
+    assert l.nmi_create(C.byref(p), C.byref(h)) == capi.ERR_INVALID_ARGUMENT
+    l.nmi_params_default(C.byref(p), 64, 48)
+    p.bins = 100
+    assert l.nmi_create(C.byref(p), C.byref(h)) == capi.ERR_UNSUPPORTED
+    l.nmi_params_default(C.byref(p), 8192, 8192)
+    assert l.nmi_create(C.byref(p), C.byref(h)) == capi.ERR_UNSUPPORTED
