@@ -153,6 +153,15 @@ int nmi_rccl_comm_destroy(void *nccl_comm);
 int nmi_set_profiling(nmi_ctx *ctx, int32_t enabled);
 int nmi_last_kernel_ms(nmi_ctx *ctx, float *h_ms);
 
+/*
+ * Tuning / ablation knobs (defaults are the shipped configuration; results stay exact for every value
+ * except NMI_OPT_HIST_VARIANT = 2, which skips the counter-wrap bookkeeping, and a partial phase mask).
+ */
+#define NMI_OPT_HIST_VARIANT 1 /* 0 per-pixel wrap test, 1 batched wrap test, 2 unchecked, 3 optimistic + verify + exact redo (default) */
+#define NMI_OPT_PHASE_MASK 2   /* bit 0 histogram phase, bit 1 decode + score; default 3 */
+#define NMI_OPT_WORKGROUPS 3   /* workgroups per launch; 0 = one per compute unit (default) */
+int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value);
+
 /* Introspection. */
 int nmi_abi_version(void);
 const char *nmi_error_string(int code);

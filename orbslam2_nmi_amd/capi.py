@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = (
     "nmi_params_default", "nmi_create", "nmi_destroy", "nmi_set_stream", "nmi_eval_pair", "nmi_eval_pair_debug",
     "nmi_search_grid", "nmi_search_grid_shard", "nmi_key_pack", "nmi_key_unpack", "nmi_search_grid_rccl",
     "nmi_rccl_unique_id", "nmi_rccl_comm_init", "nmi_rccl_comm_destroy", "nmi_set_profiling", "nmi_last_kernel_ms",
-    "nmi_abi_version", "nmi_error_string", "nmi_last_error_detail", "nmi_get_info",
+    "nmi_set_option", "nmi_abi_version", "nmi_error_string", "nmi_last_error_detail", "nmi_get_info",
 )
 
 
@@ -78,6 +78,7 @@ def load_library(build_if_missing=False):
     lib.nmi_rccl_unique_id.argtypes = [C.POINTER(C.c_uint8)]
     lib.nmi_rccl_comm_init.argtypes = [vp, C.POINTER(C.c_uint8), i32, i32, C.POINTER(vp)]
     lib.nmi_rccl_comm_destroy.argtypes = [vp]
+    lib.nmi_set_option.argtypes = [vp, i32, C.c_int64]
     lib.nmi_set_profiling.argtypes = [vp, i32]
     lib.nmi_last_kernel_ms.argtypes = [vp, f32p]
     lib.nmi_error_string.argtypes = [C.c_int]
@@ -165,6 +166,11 @@ class NmiContext:
     def set_stream(self, stream_handle):
         """Run on this hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); None = own stream."""
         self._check(self._lib.nmi_set_stream(self._h, C.c_void_p(stream_handle)), "nmi_set_stream")
+
+    OPT_HIST_VARIANT, OPT_PHASE_MASK, OPT_WORKGROUPS = 1, 2, 3
+
+    def set_option(self, option, value):
+        self._check(self._lib.nmi_set_option(self._h, int(option), int(value)), "nmi_set_option")
 
     def set_profiling(self, on):
         self._check(self._lib.nmi_set_profiling(self._h, int(bool(on))), "nmi_set_profiling")

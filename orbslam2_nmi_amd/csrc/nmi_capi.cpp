@@ -30,6 +30,9 @@ struct nmi_ctx {
     unsigned long long *h_key = nullptr;  // pinned host mirror
     float *d_pair_rating = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    int hist_variant = 3;
+    int phase_mask = 3;
+    int workgroups = 0;
     bool profiling = false;
     bool have_timing = false;
     std::string detail;
@@ -106,11 +109,14 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     a.dbg_h1 = dbg_h1;
     a.dbg_h2 = dbg_h2;
     a.dbg_sums = dbg_sums;
+    a.hist_variant = ctx->hist_variant;
+    a.phase_mask = ctx->phase_mask;
 
     NMI_HIP_TRY(ctx, hipMemsetAsync(d_key, 0, sizeof(unsigned long long), ctx->stream));
     const int64_t total = (int64_t)S_local * Wn;
     if (total == 0) return NMI_OK;
-    const int workgroups = (int)(total < ctx->compute_units ? total : ctx->compute_units);
+    const int cap = ctx->workgroups > 0 ? ctx->workgroups : ctx->compute_units;
+    const int workgroups = (int)(total < cap ? total : cap);
     if (ctx->profiling) NMI_HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     NMI_HIP_TRY(ctx, nmi::launch_grid(a, workgroups, p.use_bg != 0, ctx->stream));
     if (ctx->profiling) {
@@ -256,6 +262,27 @@ int nmi_set_stream(nmi_ctx *ctx, void *stream)
     if (!ctx) return NMI_ERR_INVALID_ARGUMENT;
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
     return NMI_OK;
+}
+
+int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value)
+{
+    if (!ctx) return NMI_ERR_INVALID_ARGUMENT;
+    switch (option) {
+    case NMI_OPT_HIST_VARIANT:
+        if (value < 0 || value > 3) return NMI_ERR_INVALID_ARGUMENT;
+        ctx->hist_variant = (int)value;
+        return NMI_OK;
+    case NMI_OPT_PHASE_MASK:
+        if (value < 0 || value > 3) return NMI_ERR_INVALID_ARGUMENT;
+        ctx->phase_mask = (int)value;
+        return NMI_OK;
+    case NMI_OPT_WORKGROUPS:
+        if (value < 0 || value > (1 << 20)) return NMI_ERR_INVALID_ARGUMENT;
+        ctx->workgroups = (int)value;
+        return NMI_OK;
+    default:
+        return NMI_ERR_INVALID_ARGUMENT;
+    }
 }
 
 int nmi_set_profiling(nmi_ctx *ctx, int32_t enabled)

@@ -26,6 +26,8 @@ struct GridArgs {
     unsigned long long *key;      // packed arg-max slot
     uint32_t *dbg_joint, *dbg_h1, *dbg_h2;
     float *dbg_sums;
+    int hist_variant;             // 0 per-pixel wrap test, 1 batched wrap test, 2 unchecked (ablation), 3 optimistic + verify (default)
+    int phase_mask;               // bit 0 histogram phase, bit 1 decode + score (ablation; product uses 3)
 };
 
 hipError_t launch_table(float *table, int npix, hipStream_t stream);

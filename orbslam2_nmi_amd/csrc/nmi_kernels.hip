@@ -27,6 +27,7 @@ constexpr int kBins = 256;
 constexpr int kWords = kBins * kBins / 2;  // two 16-bit counters per LDS word
 constexpr int kOvfCap = 1024;              // >= 2 * floor(2^24 / 65536) + 1 wrap events per candidate
 constexpr int kRowsPerWave = kBins / kWaves;
+constexpr int kLdsTable = 4096;            // per-count entropy terms kept in LDS for counts below this
 
 // LDS word of joint bin (d1 = render intensity, d2 = warped-frame intensity):
 //   word = d1 * 128 + (d2 & 127), low half for d2 < 128, high half for d2 >= 128.
@@ -40,26 +41,56 @@ struct Lds {
     uint32_t hist_render[kBins];
     uint32_t hist_warped[kBins];
     float joint_row_sums[kBins];  // d_JointEntropyShort, kernel.cu:60,90
-    uint32_t ovf[kOvfCap];        // wrap events: (word << 1) | field
-    uint32_t ovf_n;
-    float sums[3];
+    uint32_t ovf[2][kOvfCap];     // wrap events: (word << 1) | field; double-buffered by candidate parity
+    uint32_t ovf_n[2];
+    uint32_t total[2];            // sum of all decoded counters of the candidate (wrap detector), by parity
+    float table[kLdsTable];       // table[c] for c < kLdsTable (16 KiB); larger counts read the global table
 };
 
-__device__ __forceinline__ float wave_tree_64(float x)
+// ---- cross-lane helpers (DPP within a row of 16 lanes: lane i receives lane i + N) -------------------
+template <int N>
+__device__ __forceinline__ float row_shl(float x)
 {
-    // tree steps n = 32,16,...,1 over one value per lane: lane t < n takes a[t] += a[t + n].
-#pragma unroll
-    for (int n = 32; n >= 1; n >>= 1) x = x + __shfl_down(x, n, 64);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x100 + N, 0xF, 0xF, true));
+}
+template <int N>
+__device__ __forceinline__ uint32_t row_shl(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x100 + N, 0xF, 0xF, true);
+}
+// Tree steps n = 8,4,2,1 over one value per lane of a 16-lane row: lane t < n takes a[t] += a[t + n];
+// the sum ends in lane 0 of the row.
+__device__ __forceinline__ float row_tree_16(float x)
+{
+    x = x + row_shl<8>(x);
+    x = x + row_shl<4>(x);
+    x = x + row_shl<2>(x);
+    x = x + row_shl<1>(x);
     return x;
 }
-
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x)
+__device__ __forceinline__ uint32_t row_sum_16(uint32_t x)
 {
-#pragma unroll
-    for (int n = 32; n >= 1; n >>= 1) x += __shfl_down(x, n, 64);
+    x += row_shl<8>(x);
+    x += row_shl<4>(x);
+    x += row_shl<2>(x);
+    x += row_shl<1>(x);
     return x;
 }
+// In-lane part of the 256-element stride-halving tree for a lane that owns elements
+// t = i + 16*j (j = 0..15, any rotation of j): steps n = 128, 64, 32, 16 pair j with j + n/16.
+__device__ __forceinline__ float lane_tree_16(const float (&lo)[8], const float (&hi)[8])
+{
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = lo[k] + hi[k];  // n = 128
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = s[k] + s[k + 4];  // n = 64
+    s[0] = s[0] + s[2];                                  // n = 32
+    s[1] = s[1] + s[3];
+    return s[0] + s[1];                                  // n = 16
+}
 
+// ---- histogram phase -------------------------------------------------------------------------------
 // One pixel -> one LDS atomic on the packed joint histogram (the reference does three atomics per
 // pixel, NMI.cu:46-48; the marginals are recovered as row / column sums of the joint).
 // Each 16-bit field is only ever incremented by one, by an add that returns the old word, so every
@@ -67,58 +98,137 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x)
 // high field then counts d2>=128 hits plus low wraps), a high-field wrap is seen either by a high
 // add (old high == 0xFFFF) or by the carrying low add (old word == 0xFFFFFFFF).  Events are rare
 // (at most about 2 * W*H / 65536 per candidate) and are replayed when the counters are decoded.
+__device__ __forceinline__ uint32_t joint_word(uint32_t d1, uint32_t d2) { return (d1 << 7) | (d2 & 127u); }
+__device__ __forceinline__ uint32_t joint_inc(uint32_t d2) { return (d2 & 128u) ? 0x10000u : 1u; }
+
+__device__ __forceinline__ void record_wrap(Lds &lds, int par, uint32_t word, uint32_t val, uint32_t old)
+{
+    uint32_t k = __hip_atomic_fetch_add(&lds.ovf_n[par], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (k < kOvfCap) lds.ovf[par][k] = (word << 1) | (val >> 16);
+    if (val == 1u && old == 0xFFFFFFFFu) {
+        k = __hip_atomic_fetch_add(&lds.ovf_n[par], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (k < kOvfCap) lds.ovf[par][k] = (word << 1) | 1u;
+    }
+}
+
 template <bool BG, bool SHIFTED>
-__device__ __forceinline__ void add_pixel(Lds &lds, uint32_t d1, uint32_t d2, int shift)
+__device__ __forceinline__ void add_pixel(Lds &lds, int par, uint32_t d1, uint32_t d2, int shift)
 {
     if (!BG && (d1 == 0 || d2 == 0)) return;  // NMI.cu:85
     if (SHIFTED) {
         d1 >>= shift;
         d2 >>= shift;
     }
-    const uint32_t word = (d1 << 7) | (d2 & 127u);
-    const uint32_t val = (d2 & 128u) ? 0x10000u : 1u;
+    const uint32_t word = joint_word(d1, d2), val = joint_inc(d2);
     const uint32_t old = __hip_atomic_fetch_add(&lds.joint[word], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const uint32_t field = val * 0xFFFFu;
-    if (__builtin_expect((old & field) == field, 0)) {
-        uint32_t k = __hip_atomic_fetch_add(&lds.ovf_n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (k < kOvfCap) lds.ovf[k] = (word << 1) | (val >> 16);
-        if (val == 1u && old == 0xFFFFFFFFu) {
-            k = __hip_atomic_fetch_add(&lds.ovf_n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (k < kOvfCap) lds.ovf[k] = (word << 1) | 1u;
+    if (__builtin_expect((old & field) == field, 0)) record_wrap(lds, par, word, val, old);
+}
+
+// 16 pixels of one lane.  HIST selects how wraps of the 16-bit counters are handled:
+//   0  returning atomic + test per pixel (serialises on the LDS round trip; kept as the ablation baseline)
+//   1  16 returning atomics in flight, one combined wrap test per 16 pixels (default; always exact)
+//   2  non-returning atomics, no test: exact only when no bin can exceed 65535 (first try of the
+//      optimistic scheme HIST = 3, see nmi_grid_kernel)
+template <bool BG, bool SHIFTED, int HIST>
+__device__ __forceinline__ void add_chunk(Lds &lds, int par, const uint4 &rv, const uint4 &wv, int shift)
+{
+    const uint32_t r[4] = {rv.x, rv.y, rv.z, rv.w};
+    const uint32_t w[4] = {wv.x, wv.y, wv.z, wv.w};
+    if (HIST == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                add_pixel<BG, SHIFTED>(lds, par, (r[q] >> (8 * j)) & 0xFFu, (w[q] >> (8 * j)) & 0xFFu, shift);
+        return;
+    }
+    uint32_t old[16];
+    uint32_t any = 0;  // max over pixels of (old | ~field): 0xFFFFFFFF iff some counter wrapped
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t d1 = (r[q] >> (8 * j)) & 0xFFu, d2 = (w[q] >> (8 * j)) & 0xFFu;
+            const bool skip = !BG && (d1 == 0 || d2 == 0);  // NMI.cu:85
+            if (SHIFTED) {
+                d1 >>= shift;
+                d2 >>= shift;
+            }
+            const uint32_t word = joint_word(d1, d2), val = joint_inc(d2);
+            if (HIST == 2) {
+                if (!skip) (void)__hip_atomic_fetch_add(&lds.joint[word], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                old[q * 4 + j] = 0;
+                if (!skip)
+                    old[q * 4 + j] = __hip_atomic_fetch_add(&lds.joint[word], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    if (HIST == 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t d2 = (w[q] >> (8 * j)) & 0xFFu;
+                if (SHIFTED) d2 >>= shift;
+                const uint32_t notfield = (d2 & 128u) ? 0x0000FFFFu : 0xFFFF0000u;
+                const uint32_t t = old[q * 4 + j] | notfield;
+                any = t > any ? t : any;
+            }
+        if (__builtin_expect(any == 0xFFFFFFFFu, 0)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t d1 = (r[q] >> (8 * j)) & 0xFFu, d2 = (w[q] >> (8 * j)) & 0xFFu;
+                    const bool skip = !BG && (d1 == 0 || d2 == 0);
+                    if (SHIFTED) {
+                        d1 >>= shift;
+                        d2 >>= shift;
+                    }
+                    const uint32_t val = joint_inc(d2), field = val * 0xFFFFu;
+                    if (!skip && (old[q * 4 + j] & field) == field) record_wrap(lds, par, joint_word(d1, d2), val, old[q * 4 + j]);
+                }
         }
     }
 }
 
-template <bool BG, bool SHIFTED>
-__device__ __forceinline__ void add_dword(Lds &lds, uint32_t r, uint32_t w, int shift)
-{
-#pragma unroll
-    for (int j = 0; j < 4; ++j) add_pixel<BG, SHIFTED>(lds, (r >> (8 * j)) & 0xFFu, (w >> (8 * j)) & 0xFFu, shift);
-}
-
 // Histogram phase for one candidate: histogram256Kernel's pixel loop, NMI.cu:79-87.
-template <bool BG, bool SHIFTED>
-__device__ __forceinline__ void histogram_phase(Lds &lds, const GridArgs &a, const uint8_t *__restrict__ render,
+template <bool BG, bool SHIFTED, int HIST>
+__device__ __forceinline__ void histogram_phase(Lds &lds, int par, const GridArgs &a, const uint8_t *__restrict__ render,
                                                 const uint8_t *__restrict__ warped)
 {
     const int tid = threadIdx.x;
     if (a.vec_ok) {
-        // 16 pixels per lane per step: one 16-byte load from each image, 1 KiB per wavefront instruction.
+        // 16 pixels per lane per step: one 16-byte load from each image (1 KiB per wavefront instruction),
+        // the next step's loads issued before this step's atomics.
         const int nchunks = a.npix >> 4;
         const uint4 *__restrict__ wp = reinterpret_cast<const uint4 *>(warped);
-        for (int ch = tid; ch < nchunks; ch += kBlock) {
-            int rch = ch;
-            if (a.flip) {  // NMI.cu:82: row y of the frame meets row H-1-y of the bottom-up render
-                const int y = (a.chunks_per_row == 1) ? ch : (int)__umulhi((uint32_t)ch, a.cpr_magic);
-                const int cx = ch - y * a.chunks_per_row;
-                rch = (a.height - 1 - y) * a.chunks_per_row + cx;
+        const uint4 *__restrict__ rp = reinterpret_cast<const uint4 *>(render);
+        auto render_chunk = [&](int ch) {
+            if (!a.flip) return ch;
+            // NMI.cu:82: row y of the frame meets row H-1-y of the bottom-up render
+            const int y = (a.chunks_per_row == 1) ? ch : (int)__umulhi((uint32_t)ch, a.cpr_magic);
+            return (a.height - 1 - y) * a.chunks_per_row + (ch - y * a.chunks_per_row);
+        };
+        int ch = tid;
+        uint4 rv = {0, 0, 0, 0}, wv = {0, 0, 0, 0};
+        if (ch < nchunks) {
+            wv = wp[ch];
+            rv = rp[render_chunk(ch)];
+        }
+        while (ch < nchunks) {
+            const int nx = ch + kBlock;
+            uint4 rn = {0, 0, 0, 0}, wn = {0, 0, 0, 0};
+            if (nx < nchunks) {
+                wn = wp[nx];
+                rn = rp[render_chunk(nx)];
             }
-            const uint4 wv = wp[ch];
-            const uint4 rv = reinterpret_cast<const uint4 *>(render)[rch];
-            add_dword<BG, SHIFTED>(lds, rv.x, wv.x, a.shift);
-            add_dword<BG, SHIFTED>(lds, rv.y, wv.y, a.shift);
-            add_dword<BG, SHIFTED>(lds, rv.z, wv.z, a.shift);
-            add_dword<BG, SHIFTED>(lds, rv.w, wv.w, a.shift);
+            add_chunk<BG, SHIFTED, HIST>(lds, par, rv, wv, a.shift);
+            rv = rn;
+            wv = wn;
+            ch = nx;
         }
     } else {
         // Any width / alignment: byte loads, position arithmetic as written in NMI.cu:79-83.
@@ -126,7 +236,19 @@ __device__ __forceinline__ void histogram_phase(Lds &lds, const GridArgs &a, con
             const int y = pos / a.width;
             const int x = pos - y * a.width;
             const int ry = a.flip ? (a.height - 1 - y) : y;
-            add_pixel<BG, SHIFTED>(lds, render[ry * a.width + x], warped[pos], a.shift);
+            if (HIST == 2) {
+                uint32_t d1 = render[ry * a.width + x], d2 = warped[pos];
+                if (BG || (d1 != 0 && d2 != 0)) {
+                    if (SHIFTED) {
+                        d1 >>= a.shift;
+                        d2 >>= a.shift;
+                    }
+                    (void)__hip_atomic_fetch_add(&lds.joint[joint_word(d1, d2)], joint_inc(d2), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            } else {
+                add_pixel<BG, SHIFTED>(lds, par, render[ry * a.width + x], warped[pos], a.shift);
+            }
         }
     }
 }
@@ -136,12 +258,20 @@ __device__ __forceinline__ float term(const float *__restrict__ table, uint32_t 
     // ComputeEntropyKernel, NMI.cu:242-263; table[c] = (c/len) * log2f(c/len), table[0] = 0.
     return c ? table[c] : 0.0f;
 }
+// Same value, served from the LDS copy of the table for the (overwhelmingly common) small counts.
+__device__ __forceinline__ float term_lds(const Lds &lds, const float *__restrict__ table, uint32_t c)
+{
+    float t = lds.table[c < (uint32_t)kLdsTable ? c : 0u];
+    if (__builtin_expect(c >= (uint32_t)kLdsTable, 0)) t = table[c];
+    return t;
+}
 
 // Replays the wrap events of one LDS word onto its two decoded counters.
-__device__ __forceinline__ void apply_wraps(const Lds &lds, uint32_t novf, uint32_t word, uint32_t &lo, uint32_t &hi)
+__device__ __forceinline__ void apply_wraps(const Lds &lds, int par, uint32_t novf, uint32_t word, uint32_t &lo,
+                                            uint32_t &hi)
 {
     for (uint32_t e = 0; e < novf; ++e) {
-        const uint32_t ev = lds.ovf[e];
+        const uint32_t ev = lds.ovf[par][e];
         if ((ev >> 1) == word) {
             if (ev & 1u) {
                 hi += 65536u;
@@ -153,136 +283,200 @@ __device__ __forceinline__ void apply_wraps(const Lds &lds, uint32_t novf, uint3
     }
 }
 
+// ---- decode phase: counters -> per-bin terms -> row trees (ComputeEntropyKernel + AddvectorParwiseMidKernel) ----
+// A wavefront takes 4 joint rows per pass, one per 16-lane DPP row.  Lane i of a row owns the bins
+// d2 = i + 16*j (j = 0..15): words i + 16*k (k = 0..7) hold the pairs (d2, d2 + 128).  Every tree step
+// n >= 16 of NMI.cu:276-284 then pairs two values of the same lane and the steps n = 8..1 are DPP
+// shifts inside the 16-lane row: no LDS traffic besides reading (and clearing) the counters.
+// Odd DPP rows start at k = 1 so that the two rows of a 32-lane LDS access group hit disjoint banks.
+__device__ __forceinline__ void decode_phase(Lds &lds, int par, const GridArgs &a, int wave, int lane)
+{
+    const uint32_t novf = lds.ovf_n[par] < (uint32_t)kOvfCap ? lds.ovf_n[par] : (uint32_t)kOvfCap;
+    uint32_t wave_total = 0;
+    const int i = lane & 15, r = lane >> 4, o = r & 1;
+    uint32_t col_lo[8], col_hi[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) col_lo[k] = col_hi[k] = 0;
+#pragma unroll 1
+    for (int pass = 0; pass < kRowsPerWave / 4; ++pass) {
+        const int d1 = wave * kRowsPerWave + pass * 4 + r;
+        const uint32_t a0 = d1 * 128 + i + 16 * o;
+        uint32_t lo[8], hi[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t idx = k < 7 ? a0 + 16 * k : a0 + 112 - 128 * o;
+            const uint32_t wd = lds.joint[idx];
+            lds.joint[idx] = 0;  // ready for the next candidate
+            lo[k] = wd & 0xFFFFu;
+            hi[k] = wd >> 16;
+        }
+        if (__builtin_expect(novf != 0, 0)) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) apply_wraps(lds, par, novf, k < 7 ? a0 + 16 * k : a0 + 112 - 128 * o, lo[k], hi[k]);
+        }
+        uint32_t rsum = 0, cmax = 0;
+        float tl[8], th[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            col_lo[k] += lo[k];
+            col_hi[k] += hi[k];
+            rsum += lo[k] + hi[k];
+            cmax = max(cmax, max(lo[k], hi[k]));
+            // straight-line LDS lookups; counts beyond the LDS table are patched below (one branch per pass)
+            tl[k] = lds.table[lo[k] & (kLdsTable - 1)];
+            th[k] = lds.table[hi[k] & (kLdsTable - 1)];
+        }
+        if (__builtin_expect(cmax >= (uint32_t)kLdsTable, 0)) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (lo[k] >= (uint32_t)kLdsTable) tl[k] = a.table[lo[k]];
+                if (hi[k] >= (uint32_t)kLdsTable) th[k] = a.table[hi[k]];
+            }
+        }
+        rsum = row_sum_16(rsum);
+        wave_total += rsum;
+        const float x = row_tree_16(lane_tree_16(tl, th));
+        if (i == 0) {
+            lds.hist_render[d1] = rsum;
+            lds.joint_row_sums[d1] = x;
+        }
+        if (a.dbg_joint) {
+            uint32_t *row = a.dbg_joint + d1 * kBins;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int q = (i + 16 * (k + o)) & 127;
+                row[q] = lo[k];
+                row[q + 128] = hi[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int q = (i + 16 * (k + o)) & 127;
+        atomicAdd(&lds.hist_warped[q], col_lo[k]);
+        atomicAdd(&lds.hist_warped[q + 128], col_hi[k]);
+    }
+    if (i == 0) atomicAdd(&lds.total[par], wave_total);
+}
+
+// Final stage, one wavefront: the three 256-element trees of AddVectorPairwiseKernel (NMI.cu:295-339) run
+// side by side in DPP rows 0 (render marginal), 1 (frame marginal), 2 (joint row sums); then the score.
+__device__ __forceinline__ void final_phase(Lds &lds, const GridArgs &a, int lane, int p, int w, int s)
+{
+    const int i = lane & 15, r = lane >> 4;
+    float lo[8], hi[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int t = i + 16 * k;
+        if (r == 2) {
+            lo[k] = lds.joint_row_sums[t];
+            hi[k] = lds.joint_row_sums[t + 128];
+        } else if (r < 2) {
+            const uint32_t *h = r == 0 ? lds.hist_render : lds.hist_warped;
+            lo[k] = term(a.table, h[t]);
+            hi[k] = term(a.table, h[t + 128]);
+        } else {
+            lo[k] = hi[k] = 0.0f;
+        }
+    }
+    const float x = row_tree_16(lane_tree_16(lo, hi));
+    const float a1 = __shfl(x, 0, 64), a2 = __shfl(x, 16, 64), a3 = __shfl(x, 32, 64);
+    if (a.dbg_h1 && lane < 64) {
+        for (int t = lane; t < kBins; t += 64) {
+            a.dbg_h1[t] = lds.hist_render[t];
+            if (a.dbg_h2) a.dbg_h2[t] = lds.hist_warped[t];
+        }
+    }
+    if (lane == 0) {
+        // NMI.cu:342-362, evaluated from the three completed sums (the reference reads them across
+        // blocks without synchronisation, NMI.cu:340-342).
+        float score;
+        if (a1 == 0.0f && a2 == 0.0f && a3 == 0.0f)
+            score = 0.0f;
+        else if (a.mode == NMI_MODE_ENMI_)
+            score = ((-a1) + (-a2)) / (-a3);
+        else if (a.mode == NMI_MODE_SUC_)
+            score = 2.0f * (1.0f - ((-a3) / ((-a1) + (-a2))));
+        else
+            score = -1.0f;
+        if (a.ratings) a.ratings[p] = score;
+        if (a.dbg_sums) {
+            a.dbg_sums[0] = a1;
+            a.dbg_sums[1] = a2;
+            a.dbg_sums[2] = a3;
+        }
+        // find_max_elements, helperFunctions.cpp:52-101: max starts at 0, strict '>', first cell equal to
+        // the max wins.  Non-negative floats order like their bit patterns, so one 64-bit max of
+        // (score bits, inverted global index) reproduces it; negative / NaN scores contribute nothing.
+        if (score >= 0.0f) {
+            const uint32_t bits = score == 0.0f ? 0u : __float_as_uint(score);
+            const uint32_t gidx = (uint32_t)w * (uint32_t)a.S_total + (uint32_t)(a.s_offset + s);
+            const unsigned long long key = ((unsigned long long)bits << 32) | (unsigned long long)(0xFFFFFFFFu - gidx);
+            atomicMax(a.key, key);
+        }
+    }
+}
+
 }  // namespace
 
 // One workgroup per candidate (grid-stride over the candidates of this launch).
-template <bool BG, bool SHIFTED>
+//
+// HIST = 3 (default with BG on): the histogram phase uses non-returning atomics and no wrap test; the
+// decode phase sums every decoded counter, and since a wrapped 16-bit field always loses weight
+// (a low wrap turns 65536 hits into one carry, a high wrap drops 65536), the sum equals the pixel
+// count iff no field wrapped.  A candidate that fails the test is simply histogrammed again with the
+// exact wrap bookkeeping (HIST = 1 path); only frames with a bin above 65535 hits ever pay that.
+//
+// Two barriers per candidate: B1 histogram -> decode, B2 decode -> (wavefront 0: three final trees +
+// score + arg-max) || (all other wavefronts: next candidate's histogram phase).  The small per-candidate
+// state that the two sides would share is double-buffered by candidate parity.
+template <bool BG, bool SHIFTED, int HIST>
 __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
 {
     __shared__ Lds lds;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    constexpr bool kOptimistic = HIST == 3;
+    constexpr int kFirst = kOptimistic ? 2 : HIST;
 
     for (int i = tid; i < kWords; i += kBlock) lds.joint[i] = 0;
     if (tid < kBins) lds.hist_warped[tid] = 0;
-    if (tid == 0) lds.ovf_n = 0;
+    if (tid < 2) lds.ovf_n[tid] = lds.total[tid] = 0;
+    for (int i = tid; i < kLdsTable; i += kBlock) lds.table[i] = i <= a.npix ? a.table[i] : 0.0f;
     __syncthreads();
 
     const int total = a.S_local * a.Wn;
-    for (int p = blockIdx.x; p < total; p += gridDim.x) {
+    int par = 0;
+    for (int p = blockIdx.x; p < total; p += gridDim.x, par ^= 1) {
         const int w = p / a.S_local;
         const int s = p - w * a.S_local;
         const uint8_t *render = a.render_stack + (size_t)s * a.npix;
         const uint8_t *warped = a.warp_stack + (size_t)w * a.npix;
 
-        histogram_phase<BG, SHIFTED>(lds, a, render, warped);
-        __syncthreads();
-
-        // ---- decode + per-bin terms + row trees (ComputeEntropyKernel + AddvectorParwiseMidKernel) ----
-        const uint32_t novf = lds.ovf_n < (uint32_t)kOvfCap ? lds.ovf_n : (uint32_t)kOvfCap;
-        uint32_t col0 = 0, col1 = 0, col2 = 0, col3 = 0;  // column sums for d2 = lane, +64, +128, +192
-#pragma unroll 4
-        for (int k = 0; k < kRowsPerWave; ++k) {
-            const int d1 = wave * kRowsPerWave + k;
-            const uint32_t i0 = d1 * 128 + lane, i1 = i0 + 64;
-            const uint32_t w0 = lds.joint[i0], w1 = lds.joint[i1];
-            lds.joint[i0] = 0;  // ready for the next candidate
-            lds.joint[i1] = 0;
-            uint32_t c0 = w0 & 0xFFFFu, c2 = w0 >> 16, c1 = w1 & 0xFFFFu, c3 = w1 >> 16;
-            if (novf) {
-                apply_wraps(lds, novf, i0, c0, c2);
-                apply_wraps(lds, novf, i1, c1, c3);
-            }
-            col0 += c0;
-            col1 += c1;
-            col2 += c2;
-            col3 += c3;
-            const uint32_t rsum = wave_sum_u32(c0 + c1 + c2 + c3);
-            const float e0 = term(a.table, c0), e1 = term(a.table, c1), e2 = term(a.table, c2), e3 = term(a.table, c3);
-            const float x0 = e0 + e2;  // n = 128: a[t] += a[t+128], t = lane
-            const float x1 = e1 + e3;  //          a[t] += a[t+128], t = lane + 64
-            float x = x0 + x1;         // n = 64
-            x = wave_tree_64(x);       // n = 32..1
+        if (a.phase_mask & 1) histogram_phase<BG, SHIFTED, kFirst>(lds, par, a, render, warped);
+        __syncthreads();  // B1
+        if (a.phase_mask & 2) decode_phase(lds, par, a, wave, lane);
+        __syncthreads();  // B2
+        if (kOptimistic && a.phase_mask == 3 && lds.total[par] != (uint32_t)a.npix) {
+            // Some counter wrapped (workgroup-uniform, rare): redo this candidate exactly.
+            __syncthreads();
+            if (tid < kBins) lds.hist_warped[tid] = 0;
+            if (tid == 0) lds.total[par] = 0;
+            __syncthreads();
+            histogram_phase<BG, SHIFTED, 1>(lds, par, a, render, warped);
+            __syncthreads();
+            decode_phase(lds, par, a, wave, lane);
+            __syncthreads();
+        }
+        if (wave == 0) {
+            if (a.phase_mask & 2) final_phase(lds, a, lane, p, w, s);
+            for (int t = lane; t < kBins; t += 64) lds.hist_warped[t] = 0;
             if (lane == 0) {
-                lds.hist_render[d1] = rsum;
-                lds.joint_row_sums[d1] = x;
-            }
-            if (a.dbg_joint) {
-                uint32_t *row = a.dbg_joint + d1 * kBins;
-                row[lane] = c0;
-                row[lane + 64] = c1;
-                row[lane + 128] = c2;
-                row[lane + 192] = c3;
+                lds.ovf_n[par] = 0;       // consumed by this candidate's decode; next used two candidates on
+                lds.total[par ^ 1] = 0;   // read by everyone right after the previous B2; next candidate adds to it
             }
         }
-        atomicAdd(&lds.hist_warped[lane], col0);
-        atomicAdd(&lds.hist_warped[lane + 64], col1);
-        atomicAdd(&lds.hist_warped[lane + 128], col2);
-        atomicAdd(&lds.hist_warped[lane + 192], col3);
-        __syncthreads();
-
-        // ---- three 256-element trees (AddVectorPairwiseKernel, NMI.cu:295-339) ----
-        if (wave < 3) {
-            float v0, v1, v2, v3;
-            if (wave == 2) {
-                v0 = lds.joint_row_sums[lane];
-                v1 = lds.joint_row_sums[lane + 64];
-                v2 = lds.joint_row_sums[lane + 128];
-                v3 = lds.joint_row_sums[lane + 192];
-            } else {
-                const uint32_t *h = wave == 0 ? lds.hist_render : lds.hist_warped;
-                v0 = term(a.table, h[lane]);
-                v1 = term(a.table, h[lane + 64]);
-                v2 = term(a.table, h[lane + 128]);
-                v3 = term(a.table, h[lane + 192]);
-                uint32_t *o = wave == 0 ? a.dbg_h1 : a.dbg_h2;
-                if (o) {
-                    o[lane] = h[lane];
-                    o[lane + 64] = h[lane + 64];
-                    o[lane + 128] = h[lane + 128];
-                    o[lane + 192] = h[lane + 192];
-                }
-            }
-            const float x0 = v0 + v2, x1 = v1 + v3;
-            const float x = wave_tree_64(x0 + x1);
-            if (lane == 0) lds.sums[wave] = x;
-        }
-        __syncthreads();
-
-        if (tid == 0) {
-            // NMI.cu:342-362, evaluated from the three completed sums (the reference reads them
-            // across blocks without synchronisation, NMI.cu:340-342).
-            const float a1 = lds.sums[0], a2 = lds.sums[1], a3 = lds.sums[2];
-            float score;
-            if (a1 == 0.0f && a2 == 0.0f && a3 == 0.0f)
-                score = 0.0f;
-            else if (a.mode == NMI_MODE_ENMI_)
-                score = ((-a1) + (-a2)) / (-a3);
-            else if (a.mode == NMI_MODE_SUC_)
-                score = 2.0f * (1.0f - ((-a3) / ((-a1) + (-a2))));
-            else
-                score = -1.0f;
-            if (a.ratings) a.ratings[p] = score;
-            if (a.dbg_sums) {
-                a.dbg_sums[0] = a1;
-                a.dbg_sums[1] = a2;
-                a.dbg_sums[2] = a3;
-            }
-            // find_max_elements, helperFunctions.cpp:52-101: max starts at 0, strict '>', first cell
-            // equal to the max wins.  Non-negative floats order like their bit patterns, so one
-            // 64-bit max of (score bits, inverted global index) reproduces it; negative / NaN scores
-            // contribute nothing.
-            if (score >= 0.0f) {
-                const uint32_t bits = score == 0.0f ? 0u : __float_as_uint(score);
-                const uint32_t gidx = (uint32_t)w * (uint32_t)a.S_total + (uint32_t)(a.s_offset + s);
-                const unsigned long long key = ((unsigned long long)bits << 32) | (unsigned long long)(0xFFFFFFFFu - gidx);
-                atomicMax(a.key, key);
-            }
-        }
-        if (tid < kBins) lds.hist_warped[tid] = 0;
-        if (tid == 0) lds.ovf_n = 0;
-        __syncthreads();
     }
 }
 
@@ -310,20 +504,37 @@ hipError_t launch_table(float *table, int npix, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_grid(const GridArgs &a, int workgroups, bool use_bg, hipStream_t stream)
+template <int HIST>
+static void launch_hist(const GridArgs &a, dim3 grid, dim3 block, bool use_bg, hipStream_t stream)
 {
     const bool shifted = a.shift != 0;
-    dim3 grid(workgroups), block(kBlock);
     if (use_bg) {
         if (shifted)
-            hipLaunchKernelGGL((nmi_grid_kernel<true, true>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((nmi_grid_kernel<true, true, HIST>), grid, block, 0, stream, a);
         else
-            hipLaunchKernelGGL((nmi_grid_kernel<true, false>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((nmi_grid_kernel<true, false, HIST>), grid, block, 0, stream, a);
     } else {
         if (shifted)
-            hipLaunchKernelGGL((nmi_grid_kernel<false, true>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((nmi_grid_kernel<false, true, HIST>), grid, block, 0, stream, a);
         else
-            hipLaunchKernelGGL((nmi_grid_kernel<false, false>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((nmi_grid_kernel<false, false, HIST>), grid, block, 0, stream, a);
+    }
+}
+
+hipError_t launch_grid(const GridArgs &a, int workgroups, bool use_bg, hipStream_t stream)
+{
+    dim3 grid(workgroups), block(kBlock);
+    switch (a.hist_variant) {
+    case 0: launch_hist<0>(a, grid, block, use_bg, stream); break;
+    case 1: launch_hist<1>(a, grid, block, use_bg, stream); break;
+    case 2: launch_hist<2>(a, grid, block, use_bg, stream); break;
+    default:
+        // The wrap detector of HIST = 3 needs the expected pixel count, which is W*H only with BG on.
+        if (use_bg)
+            launch_hist<3>(a, grid, block, use_bg, stream);
+        else
+            launch_hist<1>(a, grid, block, use_bg, stream);
+        break;
     }
     return hipGetLastError();
 }
