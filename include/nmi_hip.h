@@ -160,6 +160,8 @@ int nmi_last_kernel_ms(nmi_ctx *ctx, float *h_ms);
 #define NMI_OPT_HIST_VARIANT 1 /* 0 per-pixel wrap test, 1 batched wrap test, 2 unchecked, 3 optimistic + verify + exact redo (default) */
 #define NMI_OPT_PHASE_MASK 2   /* bit 0 histogram phase, bit 1 decode + score; default 3 */
 #define NMI_OPT_WORKGROUPS 3   /* workgroups per launch; 0 = one per compute unit (default) */
+#define NMI_OPT_RESULT_PATH 4  /* how the 8-byte winner reaches the host: 1 the kernel posts it to pinned host memory
+                                  and the call polls it (default), 0 hipMemcpyAsync + hipStreamSynchronize */
 int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value);
 
 /* Introspection. */

@@ -167,7 +167,7 @@ class NmiContext:
         """Run on this hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); None = own stream."""
         self._check(self._lib.nmi_set_stream(self._h, C.c_void_p(stream_handle)), "nmi_set_stream")
 
-    OPT_HIST_VARIANT, OPT_PHASE_MASK, OPT_WORKGROUPS = 1, 2, 3
+    OPT_HIST_VARIANT, OPT_PHASE_MASK, OPT_WORKGROUPS, OPT_RESULT_PATH = 1, 2, 3, 4
 
     def set_option(self, option, value):
         self._check(self._lib.nmi_set_option(self._h, int(option), int(value)), "nmi_set_option")

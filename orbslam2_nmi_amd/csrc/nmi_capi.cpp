@@ -26,8 +26,14 @@ struct nmi_ctx {
     float *table = nullptr;             // [npix + 1]
     float *ratings = nullptr;           // internal rating table
     int64_t ratings_cap = 0;
-    unsigned long long *d_key = nullptr;  // device slot for the packed winner
-    unsigned long long *h_key = nullptr;  // pinned host mirror
+    unsigned long long *d_keys = nullptr;  // two device slots for the packed winner, used alternately (ping-pong)
+    unsigned long long *h_key = nullptr;   // pinned host mirror (copy path)
+    unsigned int *d_done = nullptr;        // finished-workgroup counter
+    nmi::Mailbox *mailbox = nullptr;       // pinned, fine-grained: the kernel posts the winner here
+    unsigned int seq = 0;                  // launches so far
+    int slot = 0;                          // key slot of the next launch
+    int last_slot = 0;                     // key slot of the most recent launch
+    int result_path = 1;                   // 1 mailbox spin (default), 0 hipMemcpyAsync + stream sync
     float *d_pair_rating = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     int hist_variant = 3;
@@ -80,9 +86,9 @@ int ensure_ratings(nmi_ctx *ctx, int64_t n)
     return NMI_OK;
 }
 
-// Enqueues: key reset, the grid kernel.  No synchronisation.
+// Enqueues the grid kernel (one launch, nothing else).  No synchronisation.
 int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_offset, int S_total,
-                 const uint8_t *warp_stack, int Wn, float *d_ratings, unsigned long long *d_key, uint32_t *dbg_joint,
+                 const uint8_t *warp_stack, int Wn, float *d_ratings, unsigned long long *out_key, uint32_t *dbg_joint,
                  uint32_t *dbg_h1, uint32_t *dbg_h2, float *dbg_sums)
 {
     const nmi_params &p = ctx->params;
@@ -104,7 +110,13 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     a.flip = p.render_bottom_up ? 1 : 0;
     a.table = ctx->table;
     a.ratings = d_ratings;
-    a.key = d_key;
+    a.key = ctx->d_keys + ctx->slot;
+    a.reset_key = ctx->d_keys + (ctx->slot ^ 1);
+    a.out_key = out_key;
+    a.done = ctx->d_done;
+    a.mailbox = ctx->mailbox;
+    a.seq = ++ctx->seq;
+    ctx->last_slot = ctx->slot;
     a.dbg_joint = dbg_joint;
     a.dbg_h1 = dbg_h1;
     a.dbg_h2 = dbg_h2;
@@ -112,9 +124,17 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     a.hist_variant = ctx->hist_variant;
     a.phase_mask = ctx->phase_mask;
 
-    NMI_HIP_TRY(ctx, hipMemsetAsync(d_key, 0, sizeof(unsigned long long), ctx->stream));
     const int64_t total = (int64_t)S_local * Wn;
-    if (total == 0) return NMI_OK;
+    if (total == 0) {
+        // nothing to score: the winner is "none" (key 0); publish it the way the kernel would
+        if (out_key) NMI_HIP_TRY(ctx, hipMemsetAsync(out_key, 0, sizeof(unsigned long long), ctx->stream));
+        NMI_HIP_TRY(ctx, hipMemsetAsync(ctx->d_keys + ctx->slot, 0, sizeof(unsigned long long), ctx->stream));
+        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->mailbox->key = 0;
+        ctx->mailbox->seq = ctx->seq;
+        return NMI_OK;
+    }
+    ctx->slot ^= 1;
     const int cap = ctx->workgroups > 0 ? ctx->workgroups : ctx->compute_units;
     const int workgroups = (int)(total < cap ? total : cap);
     if (ctx->profiling) NMI_HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
@@ -123,6 +143,37 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
         NMI_HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
         ctx->have_timing = true;
     }
+    return NMI_OK;
+}
+
+// Blocks until the launch numbered ctx->seq has published its winner and returns it.
+int fetch_key(nmi_ctx *ctx, unsigned long long *key)
+{
+    if (ctx->result_path == 1) {
+        // The last workgroup stores {key, seq} to fine-grained pinned memory with a system-scope release; poll it.
+        volatile unsigned int *seq = &ctx->mailbox->seq;
+        const unsigned int want = ctx->seq;
+        for (uint64_t spin = 0;; ++spin) {
+            if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == want) {
+                *key = __atomic_load_n(&ctx->mailbox->key, __ATOMIC_RELAXED);
+                return NMI_OK;
+            }
+            if ((spin & 0xFFFF) == 0xFFFF) {
+                // a faulted or finished stream must not leave us spinning
+                const hipError_t q = hipStreamQuery(ctx->stream);
+                if (q == hipSuccess) break;  // stream drained: fall through to the copy path below
+                if (q != hipErrorNotReady) return hip_fail(ctx, q, "hipStreamQuery");
+            }
+        }
+        if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == want) {
+            *key = __atomic_load_n(&ctx->mailbox->key, __ATOMIC_RELAXED);
+            return NMI_OK;
+        }
+    }
+    NMI_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_key, ctx->d_keys + ctx->last_slot, sizeof(unsigned long long),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+    NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *key = *ctx->h_key;
     return NMI_OK;
 }
 
@@ -224,7 +275,14 @@ int nmi_create(const nmi_params *params, nmi_ctx **out_ctx)
     ctx->stream = p.stream ? (hipStream_t)p.stream : ctx->own_stream;
     if ((e = hipMalloc((void **)&ctx->table, ((size_t)ctx->npix + 1) * sizeof(float))) != hipSuccess)
         return fail(e, "hipMalloc(table)");
-    if ((e = hipMalloc((void **)&ctx->d_key, sizeof(unsigned long long))) != hipSuccess) return fail(e, "hipMalloc(key)");
+    if ((e = hipMalloc((void **)&ctx->d_keys, 2 * sizeof(unsigned long long))) != hipSuccess) return fail(e, "hipMalloc(key)");
+    if ((e = hipMalloc((void **)&ctx->d_done, sizeof(unsigned int))) != hipSuccess) return fail(e, "hipMalloc(done)");
+    if ((e = hipMemset(ctx->d_keys, 0, 2 * sizeof(unsigned long long))) != hipSuccess) return fail(e, "hipMemset(key)");
+    if ((e = hipMemset(ctx->d_done, 0, sizeof(unsigned int))) != hipSuccess) return fail(e, "hipMemset(done)");
+    if ((e = hipHostMalloc((void **)&ctx->mailbox, sizeof(nmi::Mailbox), hipHostMallocCoherent | hipHostMallocMapped)) !=
+        hipSuccess)
+        return fail(e, "hipHostMalloc(mailbox)");
+    memset(ctx->mailbox, 0, sizeof(nmi::Mailbox));
     if ((e = hipMalloc((void **)&ctx->d_pair_rating, sizeof(float))) != hipSuccess) return fail(e, "hipMalloc(rating)");
     if ((e = hipHostMalloc((void **)&ctx->h_key, sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
         return fail(e, "hipHostMalloc(key)");
@@ -247,7 +305,9 @@ int nmi_destroy(nmi_ctx *ctx)
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     if (ctx->table) (void)hipFree(ctx->table);
     if (ctx->ratings) (void)hipFree(ctx->ratings);
-    if (ctx->d_key) (void)hipFree(ctx->d_key);
+    if (ctx->d_keys) (void)hipFree(ctx->d_keys);
+    if (ctx->d_done) (void)hipFree(ctx->d_done);
+    if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
     if (ctx->d_pair_rating) (void)hipFree(ctx->d_pair_rating);
     if (ctx->h_key) (void)hipHostFree(ctx->h_key);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
@@ -275,6 +335,10 @@ int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value)
     case NMI_OPT_PHASE_MASK:
         if (value < 0 || value > 3) return NMI_ERR_INVALID_ARGUMENT;
         ctx->phase_mask = (int)value;
+        return NMI_OK;
+    case NMI_OPT_RESULT_PATH:
+        if (value < 0 || value > 1) return NMI_ERR_INVALID_ARGUMENT;
+        ctx->result_path = (int)value;
         return NMI_OK;
     case NMI_OPT_WORKGROUPS:
         if (value < 0 || value > (1 << 20)) return NMI_ERR_INVALID_ARGUMENT;
@@ -339,14 +403,14 @@ int nmi_search_grid_shard(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S_l
     int rc = check_grid_args(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn);
     if (rc != NMI_OK) return rc;
     DeviceGuard guard(ctx->device);
-    unsigned long long *key = d_key ? (unsigned long long *)d_key : ctx->d_key;
-    rc = enqueue_grid(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn, d_ratings, key, nullptr, nullptr,
-                      nullptr, nullptr);
+    rc = enqueue_grid(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn, d_ratings, (unsigned long long *)d_key,
+                      nullptr, nullptr, nullptr, nullptr);
     if (rc != NMI_OK) return rc;
     if (h_key) {
-        NMI_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_key, key, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        *h_key = *ctx->h_key;
+        unsigned long long k = 0;
+        rc = fetch_key(ctx, &k);
+        if (rc != NMI_OK) return rc;
+        *h_key = k;
     }
     return NMI_OK;
 }
@@ -366,7 +430,7 @@ int nmi_eval_pair_debug(nmi_ctx *ctx, const uint8_t *render, const uint8_t *warp
     if (!ctx || !render || !warped || !h_score) return NMI_ERR_INVALID_ARGUMENT;
     ctx->detail.clear();
     DeviceGuard guard(ctx->device);
-    int rc = enqueue_grid(ctx, render, 1, 0, 1, warped, 1, ctx->d_pair_rating, ctx->d_key, d_joint, d_hist_render,
+    int rc = enqueue_grid(ctx, render, 1, 0, 1, warped, 1, ctx->d_pair_rating, nullptr, d_joint, d_hist_render,
                           d_hist_warped, d_sums);
     if (rc != NMI_OK) return rc;
     // kernel.cu:100: the blocking 4-byte copy of the score back to the caller.
@@ -484,9 +548,10 @@ int nmi_search_grid_rccl(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S_lo
     if (rc != NMI_OK) return rc;
     DeviceGuard guard(ctx->device);
     // The only exchange of the search: 8 bytes per rank, max over ranks.
-    int r = rccl().all_reduce(ctx->d_key, ctx->d_key, 1, kNcclUint64, kNcclMax, nccl_comm, ctx->stream);
+    unsigned long long *k = ctx->d_keys + ctx->last_slot;
+    int r = rccl().all_reduce(k, k, 1, kNcclUint64, kNcclMax, nccl_comm, ctx->stream);
     if (r != 0) return rccl_fail(ctx, r, "ncclAllReduce");
-    NMI_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_key, ctx->d_key, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    NMI_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_key, k, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return nmi_key_unpack(*ctx->h_key, h_best_index, h_best_score);
 }

@@ -9,6 +9,13 @@
 
 namespace nmi {
 
+// Host-visible result slot (fine-grained pinned memory): the kernel's last workgroup writes key, then seq.
+struct Mailbox {
+    unsigned long long key;
+    unsigned int seq;
+    unsigned int pad;
+};
+
 struct GridArgs {
     const uint8_t *render_stack;  // [S_local][H][W]
     const uint8_t *warp_stack;    // [Wn][H][W]
@@ -23,7 +30,12 @@ struct GridArgs {
     int flip;                     // render stored bottom-up (NMI.cu:82)
     const float *table;           // [npix + 1] per-count entropy terms
     float *ratings;               // [Wn][S_local] or nullptr
-    unsigned long long *key;      // packed arg-max slot
+    unsigned long long *key;      // packed arg-max slot of this launch (zero on entry)
+    unsigned long long *reset_key;  // the slot of the next launch: cleared by this one (ping-pong), or nullptr
+    unsigned long long *out_key;    // optional copy of the final key for a caller / a collective
+    unsigned int *done;             // count of finished workgroups (zero on entry, left zero)
+    Mailbox *mailbox;               // pinned host memory the last workgroup posts the winner to, or nullptr
+    unsigned int seq;               // launch sequence number posted with the winner
     uint32_t *dbg_joint, *dbg_h1, *dbg_h2;
     float *dbg_sums;
     int hist_variant;             // 0 per-pixel wrap test, 1 batched wrap test, 2 unchecked (ablation), 3 optimistic + verify (default)

@@ -440,6 +440,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
     constexpr bool kOptimistic = HIST == 3;
     constexpr int kFirst = kOptimistic ? 2 : HIST;
 
+    if (blockIdx.x == 0 && tid == 0 && a.reset_key) *a.reset_key = 0ull;  // next launch's slot; idle during this one
     for (int i = tid; i < kWords; i += kBlock) lds.joint[i] = 0;
     if (tid < kBins) lds.hist_warped[tid] = 0;
     if (tid < 2) lds.ovf_n[tid] = lds.total[tid] = 0;
@@ -475,6 +476,26 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
             if (lane == 0) {
                 lds.ovf_n[par] = 0;       // consumed by this candidate's decode; next used two candidates on
                 lds.total[par ^ 1] = 0;   // read by everyone right after the previous B2; next candidate adds to it
+            }
+        }
+    }
+
+    // ---- completion: the last workgroup to finish publishes the winner -------------------------------------
+    // Every atomicMax above and the counter below are device-scope read-modify-writes performed at the memory
+    // side.  A returning no-op max on the key slot comes back only after this workgroup's earlier maxes on that
+    // address were performed, and the counter increment depends on its value; so the workgroup that sees the last
+    // count reads the final key.
+    if (tid == 0) {
+        const unsigned long long flushed = __hip_atomic_fetch_max(a.key, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int one = flushed == ~0ull ? 2u : 1u;  // always 1 (a key never has all bits set); keeps the dependency
+        const unsigned int arrived = __hip_atomic_fetch_add(a.done, one, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == gridDim.x - 1) {
+            const unsigned long long final_key = __hip_atomic_load(a.key, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.out_key) *a.out_key = final_key;
+            if (a.mailbox) {
+                __hip_atomic_store(&a.mailbox->key, final_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&a.mailbox->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }

@@ -1,0 +1,56 @@
+"""Multi-GPU form of the search (new design; the reference is single-GPU).
+
+The candidate grid shards along the render (synth) axis: rank r owns a contiguous block of renders and the whole
+warp stack, scores its block with the HIP kernel, and the ranks exchange one packed 64-bit key with a MAX
+all-reduce (torch.distributed: backend "nccl" is RCCL on ROCm; "gloo" in the CPU tests).  The key
+(nmi_key_pack, include/nmi_hip.h) orders candidates exactly like helperFunctions::find_max_elements
+(helperFunctions.cpp:50-103): larger score first, then lower global linear index.
+"""
+import numpy as np
+
+from . import capi
+
+
+def render_shard(s_total, rank, world):
+    """Contiguous block [offset, offset + count) of the render axis for `rank`; blocks differ by at most one."""
+    if not (0 <= rank < world) or s_total < 0:
+        raise ValueError("bad shard request")
+    base, extra = divmod(s_total, world)
+    count = base + (1 if rank < extra else 0)
+    offset = rank * base + min(rank, extra)
+    return offset, count
+
+
+def global_index(w, s_global, s_total):
+    """Linear index of candidate (warp w, render s_global) in the unsharded rating table [Wn][S_total]."""
+    return w * s_total + s_global
+
+
+def allreduce_key(key_tensor, dist, group=None):
+    """MAX all-reduce of the one-element int64 key tensor in place (keys are < 2^63 for non-negative scores)."""
+    dist.all_reduce(key_tensor, op=dist.ReduceOp.MAX, group=group)
+    return key_tensor
+
+
+def sharded_search(ctx, render_shard_stack, s_offset, s_total, warp_stack, key_tensor, dist=None, group=None):
+    """One rank's step: HIP kernel on the local shard -> key on the device -> all-reduce -> (index, score) on host.
+
+    ctx must run on the current torch stream (ctx.set_stream(torch.cuda.current_stream().cuda_stream)) so that the
+    collective is ordered after the kernel."""
+    ctx.search_grid_shard(render_shard_stack, s_offset, s_total, warp_stack, key_out=key_tensor, blocking=False)
+    if dist is not None:
+        allreduce_key(key_tensor, dist, group)
+    return capi.key_unpack(int(key_tensor.item()))
+
+
+def local_key_from_ratings(ratings_local, s_offset, s_total):
+    """Host restatement of what the kernel's atomicMax computes, for ratings [Wn][S_local] of one shard.
+    Used by the CPU (gloo) tests of the collective logic."""
+    r = np.asarray(ratings_local, np.float32)
+    best = 0
+    wn, s_local = r.shape
+    for w in range(wn):
+        for s in range(s_local):
+            k = capi.key_pack(float(r[w, s]), global_index(w, s_offset + s, s_total))
+            best = max(best, k)
+    return best
