@@ -28,7 +28,7 @@ def algorithmic_bytes_per_eval(w, h):
     return 2 * w * h + 4  # one u8 read of each image + one f32 score
 
 
-def cpu_baseline(wl, budget_s=12.0):
+def cpu_baseline(wl, budget_s=12.0, max_threads=16):
     """The CPU oracle (a port: the reference has no CPU NMI path) on the host cores, bounded sample."""
     from oracle import binding as oc
     # the host cores this process may use (cgroup / affinity share of the box, not the machine's total)
@@ -36,7 +36,8 @@ def cpu_baseline(wl, budget_s=12.0):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    threads = max(1, min(oc.max_threads(), avail))
+    # a 1-GPU box's CPU share is 16 cores (harness rule); never oversubscribe that
+    threads = max(1, min(oc.max_threads(), avail, max_threads))
     rs, ws = wl["render_stack"], wl["warp_stack"]
     oc.search_grid(rs[:threads], ws[:2], threads=threads, render_bottom_up=wl["bottom_up"])  # warm-up
     evals, t0 = 0, time.perf_counter()
@@ -70,6 +71,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--cpu-threads", type=int, default=16, help="cap on oracle threads for the cpu_baseline leg")
     args = ap.parse_args()
 
     import torch
@@ -182,7 +184,7 @@ def main():
                          "algorithmic_bytes_per_launch": per_launch_evals * algorithmic_bytes_per_eval(WIDTH, HEIGHT)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_budget, args.cpu_threads)
         print(json.dumps(out))
     ctx.close()
     if dist is not None:

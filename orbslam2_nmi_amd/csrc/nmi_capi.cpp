@@ -30,10 +30,11 @@ struct nmi_ctx {
     unsigned long long *h_key = nullptr;   // pinned host mirror (copy path)
     unsigned int *d_done = nullptr;        // finished-workgroup counter
     nmi::Mailbox *mailbox = nullptr;       // pinned, fine-grained: the kernel posts the winner here
-    unsigned int seq = 0;                  // launches so far
+    unsigned int seq = 0;                  // launches that post to the mailbox so far (blocking calls only)
     int slot = 0;                          // key slot of the next launch
     int last_slot = 0;                     // key slot of the most recent launch
     int result_path = 1;                   // 1 mailbox spin (default), 0 hipMemcpyAsync + stream sync
+    bool posted = false;                   // the most recent launch posts to the mailbox
     float *d_pair_rating = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     int hist_variant = 3;
@@ -88,8 +89,8 @@ int ensure_ratings(nmi_ctx *ctx, int64_t n)
 
 // Enqueues the grid kernel (one launch, nothing else).  No synchronisation.
 int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_offset, int S_total,
-                 const uint8_t *warp_stack, int Wn, float *d_ratings, unsigned long long *out_key, uint32_t *dbg_joint,
-                 uint32_t *dbg_h1, uint32_t *dbg_h2, float *dbg_sums)
+                 const uint8_t *warp_stack, int Wn, float *d_ratings, unsigned long long *out_key, bool post,
+                 uint32_t *dbg_joint, uint32_t *dbg_h1, uint32_t *dbg_h2, float *dbg_sums)
 {
     const nmi_params &p = ctx->params;
     nmi::GridArgs a{};
@@ -114,8 +115,12 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     a.reset_key = ctx->d_keys + (ctx->slot ^ 1);
     a.out_key = out_key;
     a.done = ctx->d_done;
-    a.mailbox = ctx->mailbox;
-    a.seq = ++ctx->seq;
+    // Only launches whose winner the host will poll for post to the mailbox (one bit of sequence is enough
+    // because those calls are blocking, hence strictly alternating).
+    post = post && ctx->result_path == 1;
+    a.mailbox = post ? ctx->mailbox : nullptr;
+    a.seq = post ? ++ctx->seq : 0;
+    ctx->posted = post;
     ctx->last_slot = ctx->slot;
     a.dbg_joint = dbg_joint;
     a.dbg_h1 = dbg_h1;
@@ -130,8 +135,7 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
         if (out_key) NMI_HIP_TRY(ctx, hipMemsetAsync(out_key, 0, sizeof(unsigned long long), ctx->stream));
         NMI_HIP_TRY(ctx, hipMemsetAsync(ctx->d_keys + ctx->slot, 0, sizeof(unsigned long long), ctx->stream));
         NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->mailbox->key = 0;
-        ctx->mailbox->seq = ctx->seq;
+        if (post) ctx->mailbox->word = (unsigned long long)(ctx->seq & 1u) << 63;
         return NMI_OK;
     }
     ctx->slot ^= 1;
@@ -149,13 +153,13 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
 // Blocks until the launch numbered ctx->seq has published its winner and returns it.
 int fetch_key(nmi_ctx *ctx, unsigned long long *key)
 {
-    if (ctx->result_path == 1) {
-        // The last workgroup stores {key, seq} to fine-grained pinned memory with a system-scope release; poll it.
-        volatile unsigned int *seq = &ctx->mailbox->seq;
-        const unsigned int want = ctx->seq;
+    if (ctx->posted) {
+        // The last workgroup stores (key | parity << 63) to fine-grained pinned memory; poll that one word.
+        const unsigned long long want = (unsigned long long)(ctx->seq & 1u);
         for (uint64_t spin = 0;; ++spin) {
-            if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == want) {
-                *key = __atomic_load_n(&ctx->mailbox->key, __ATOMIC_RELAXED);
+            const unsigned long long word = __atomic_load_n(&ctx->mailbox->word, __ATOMIC_ACQUIRE);
+            if ((word >> 63) == want) {
+                *key = word & 0x7FFFFFFFFFFFFFFFull;
                 return NMI_OK;
             }
             if ((spin & 0xFFFF) == 0xFFFF) {
@@ -165,8 +169,9 @@ int fetch_key(nmi_ctx *ctx, unsigned long long *key)
                 if (q != hipErrorNotReady) return hip_fail(ctx, q, "hipStreamQuery");
             }
         }
-        if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == want) {
-            *key = __atomic_load_n(&ctx->mailbox->key, __ATOMIC_RELAXED);
+        const unsigned long long word = __atomic_load_n(&ctx->mailbox->word, __ATOMIC_ACQUIRE);
+        if ((word >> 63) == want) {
+            *key = word & 0x7FFFFFFFFFFFFFFFull;
             return NMI_OK;
         }
     }
@@ -404,7 +409,7 @@ int nmi_search_grid_shard(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S_l
     if (rc != NMI_OK) return rc;
     DeviceGuard guard(ctx->device);
     rc = enqueue_grid(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn, d_ratings, (unsigned long long *)d_key,
-                      nullptr, nullptr, nullptr, nullptr);
+                      h_key != nullptr, nullptr, nullptr, nullptr, nullptr);
     if (rc != NMI_OK) return rc;
     if (h_key) {
         unsigned long long k = 0;
@@ -430,7 +435,7 @@ int nmi_eval_pair_debug(nmi_ctx *ctx, const uint8_t *render, const uint8_t *warp
     if (!ctx || !render || !warped || !h_score) return NMI_ERR_INVALID_ARGUMENT;
     ctx->detail.clear();
     DeviceGuard guard(ctx->device);
-    int rc = enqueue_grid(ctx, render, 1, 0, 1, warped, 1, ctx->d_pair_rating, nullptr, d_joint, d_hist_render,
+    int rc = enqueue_grid(ctx, render, 1, 0, 1, warped, 1, ctx->d_pair_rating, nullptr, false, d_joint, d_hist_render,
                           d_hist_warped, d_sums);
     if (rc != NMI_OK) return rc;
     // kernel.cu:100: the blocking 4-byte copy of the score back to the caller.

@@ -9,11 +9,11 @@
 
 namespace nmi {
 
-// Host-visible result slot (fine-grained pinned memory): the kernel's last workgroup writes key, then seq.
+// Host-visible result slot (fine-grained pinned memory): the kernel's last workgroup writes one 8-byte word,
+// bits 0..62 = packed winner key, bit 63 = parity of the posting launch's sequence number.
 struct Mailbox {
-    unsigned long long key;
-    unsigned int seq;
-    unsigned int pad;
+    unsigned long long word;
+    unsigned long long pad;
 };
 
 struct GridArgs {
@@ -35,7 +35,7 @@ struct GridArgs {
     unsigned long long *out_key;    // optional copy of the final key for a caller / a collective
     unsigned int *done;             // count of finished workgroups (zero on entry, left zero)
     Mailbox *mailbox;               // pinned host memory the last workgroup posts the winner to, or nullptr
-    unsigned int seq;               // launch sequence number posted with the winner
+    unsigned int seq;               // sequence number of this posting launch (its parity is posted with the winner)
     uint32_t *dbg_joint, *dbg_h1, *dbg_h2;
     float *dbg_sums;
     int hist_variant;             // 0 per-pixel wrap test, 1 batched wrap test, 2 unchecked (ablation), 3 optimistic + verify (default)

@@ -212,23 +212,25 @@ __device__ __forceinline__ void histogram_phase(Lds &lds, int par, const GridArg
             const int y = (a.chunks_per_row == 1) ? ch : (int)__umulhi((uint32_t)ch, a.cpr_magic);
             return (a.height - 1 - y) * a.chunks_per_row + (ch - y * a.chunks_per_row);
         };
+        // Software pipeline with two named register sets: the loads of the chunk after next are in flight while
+        // the current chunk's 16 atomics issue.  Loads are unconditional (index clamped to the last chunk, a valid
+        // address) so the code is straight-line and the compiler can wait on exact load counts; only the atomics
+        // are predicated on the chunk being in range.
+        const int last = nchunks - 1;
+        const int iters = (nchunks + kBlock - 1) / kBlock;  // workgroup-uniform
         int ch = tid;
-        uint4 rv = {0, 0, 0, 0}, wv = {0, 0, 0, 0};
-        if (ch < nchunks) {
-            wv = wp[ch];
-            rv = rp[render_chunk(ch)];
-        }
-        while (ch < nchunks) {
-            const int nx = ch + kBlock;
-            uint4 rn = {0, 0, 0, 0}, wn = {0, 0, 0, 0};
-            if (nx < nchunks) {
-                wn = wp[nx];
-                rn = rp[render_chunk(nx)];
-            }
-            add_chunk<BG, SHIFTED, HIST>(lds, par, rv, wv, a.shift);
-            rv = rn;
-            wv = wn;
-            ch = nx;
+        int c0 = min(ch, last);
+        uint4 wa = wp[c0], ra = rp[render_chunk(c0)], wb, rb;
+        for (int it = 0; it < iters; it += 2) {
+            const int c1 = min(ch + kBlock, last);
+            wb = wp[c1];
+            rb = rp[render_chunk(c1)];
+            if (ch < nchunks) add_chunk<BG, SHIFTED, HIST>(lds, par, ra, wa, a.shift);
+            const int c2 = min(ch + 2 * kBlock, last);
+            wa = wp[c2];
+            ra = rp[render_chunk(c2)];
+            if (ch + kBlock < nchunks) add_chunk<BG, SHIFTED, HIST>(lds, par, rb, wb, a.shift);
+            ch += 2 * kBlock;
         }
     } else {
         // Any width / alignment: byte loads, position arithmetic as written in NMI.cu:79-83.
@@ -361,7 +363,8 @@ __device__ __forceinline__ void decode_phase(Lds &lds, int par, const GridArgs &
 
 // Final stage, one wavefront: the three 256-element trees of AddVectorPairwiseKernel (NMI.cu:295-339) run
 // side by side in DPP rows 0 (render marginal), 1 (frame marginal), 2 (joint row sums); then the score.
-__device__ __forceinline__ void final_phase(Lds &lds, const GridArgs &a, int lane, int p, int w, int s)
+__device__ __forceinline__ void final_phase(Lds &lds, const GridArgs &a, int lane, int p, int w, int s,
+                                            unsigned long long &prev_key)
 {
     const int i = lane & 15, r = lane >> 4;
     float lo[8], hi[8];
@@ -412,7 +415,9 @@ __device__ __forceinline__ void final_phase(Lds &lds, const GridArgs &a, int lan
             const uint32_t bits = score == 0.0f ? 0u : __float_as_uint(score);
             const uint32_t gidx = (uint32_t)w * (uint32_t)a.S_total + (uint32_t)(a.s_offset + s);
             const unsigned long long key = ((unsigned long long)bits << 32) | (unsigned long long)(0xFFFFFFFFu - gidx);
-            atomicMax(a.key, key);
+            // returning form: the value is not needed, but its arrival (awaited once, at kernel end) proves the
+            // max was performed, which the completion protocol below builds on
+            prev_key = __hip_atomic_fetch_max(a.key, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -441,13 +446,26 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
     constexpr int kFirst = kOptimistic ? 2 : HIST;
 
     if (blockIdx.x == 0 && tid == 0 && a.reset_key) *a.reset_key = 0ull;  // next launch's slot; idle during this one
-    for (int i = tid; i < kWords; i += kBlock) lds.joint[i] = 0;
+    // The LDS copy of the term table is first needed by the first decode phase: fetch it now, park it in
+    // registers across the first histogram phase, store it before the first barrier.
+    float tab[kLdsTable / kBlock];
+#pragma unroll
+    for (int k = 0; k < kLdsTable / kBlock; ++k) {
+        const int c = tid + k * kBlock;
+        tab[k] = a.table[c <= a.npix ? c : 0];
+    }
+    {
+        uint4 *j4 = reinterpret_cast<uint4 *>(lds.joint);
+        const uint4 z = {0, 0, 0, 0};
+        for (int i = tid; i < kWords / 4; i += kBlock) j4[i] = z;
+    }
     if (tid < kBins) lds.hist_warped[tid] = 0;
     if (tid < 2) lds.ovf_n[tid] = lds.total[tid] = 0;
-    for (int i = tid; i < kLdsTable; i += kBlock) lds.table[i] = i <= a.npix ? a.table[i] : 0.0f;
+    bool table_pending = true;
     __syncthreads();
 
     const int total = a.S_local * a.Wn;
+    unsigned long long prev_key = 0;
     int par = 0;
     for (int p = blockIdx.x; p < total; p += gridDim.x, par ^= 1) {
         const int w = p / a.S_local;
@@ -456,6 +474,11 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
         const uint8_t *warped = a.warp_stack + (size_t)w * a.npix;
 
         if (a.phase_mask & 1) histogram_phase<BG, SHIFTED, kFirst>(lds, par, a, render, warped);
+        if (table_pending) {
+#pragma unroll
+            for (int k = 0; k < kLdsTable / kBlock; ++k) lds.table[tid + k * kBlock] = tab[k];
+            table_pending = false;
+        }
         __syncthreads();  // B1
         if (a.phase_mask & 2) decode_phase(lds, par, a, wave, lane);
         __syncthreads();  // B2
@@ -471,7 +494,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
             __syncthreads();
         }
         if (wave == 0) {
-            if (a.phase_mask & 2) final_phase(lds, a, lane, p, w, s);
+            if (a.phase_mask & 2) final_phase(lds, a, lane, p, w, s, prev_key);
             for (int t = lane; t < kBins; t += 64) lds.hist_warped[t] = 0;
             if (lane == 0) {
                 lds.ovf_n[par] = 0;       // consumed by this candidate's decode; next used two candidates on
@@ -482,21 +505,20 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
 
     // ---- completion: the last workgroup to finish publishes the winner -------------------------------------
     // Every atomicMax above and the counter below are device-scope read-modify-writes performed at the memory
-    // side.  A returning no-op max on the key slot comes back only after this workgroup's earlier maxes on that
-    // address were performed, and the counter increment depends on its value; so the workgroup that sees the last
-    // count reads the final key.
+    // side.  The counter increment carries a data dependency on the values returned by this workgroup's maxes,
+    // so it is issued after they were performed; the workgroup that draws the last ticket therefore reads the
+    // final key.  Nothing here needs a cache write-back: the key travels in atomics, and the mailbox is one
+    // 8-byte store (key in bits 0..62, launch parity in bit 63 -- scores are non-negative floats, bit 63 is free).
     if (tid == 0) {
-        const unsigned long long flushed = __hip_atomic_fetch_max(a.key, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned int one = flushed == ~0ull ? 2u : 1u;  // always 1 (a key never has all bits set); keeps the dependency
-        const unsigned int arrived = __hip_atomic_fetch_add(a.done, one, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int one = prev_key == ~0ull ? 2u : 1u;  // always 1 (a key never has all bits set)
+        const unsigned int arrived = __hip_atomic_fetch_add(a.done, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (arrived == gridDim.x - 1) {
-            const unsigned long long final_key = __hip_atomic_load(a.key, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long final_key = __hip_atomic_load(a.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (a.out_key) *a.out_key = final_key;
-            if (a.mailbox) {
-                __hip_atomic_store(&a.mailbox->key, final_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(&a.mailbox->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
+            if (a.mailbox)
+                __hip_atomic_store(&a.mailbox->word, final_key | ((unsigned long long)(a.seq & 1u) << 63), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
