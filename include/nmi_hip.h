@@ -80,6 +80,8 @@ int nmi_destroy(nmi_ctx *ctx);
 
 /* Run subsequent work on this hipStream_t (not owned).  NULL restores the context's own stream. */
 int nmi_set_stream(nmi_ctx *ctx, void *stream);
+/* Blocks until everything enqueued on the context's stream has finished. */
+int nmi_synchronize(nmi_ctx *ctx);
 
 /*
  * One candidate: replaces CUDAF::NMIWithCuda_noMask (Thirdparty/CUDA_Functions/kernel.cuh:37,
@@ -126,6 +128,19 @@ int nmi_search_grid(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S, const 
 int nmi_search_grid_shard(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S_local, int32_t s_offset,
                           int32_t S_total, const uint8_t *warp_stack, int32_t Wn, float *d_ratings,
                           uint64_t *d_key, uint64_t *h_key);
+
+/*
+ * Warp-stack producer: replaces Image::calculateWarping (Thirdparty/Localization/image.cpp:115-128),
+ * i.e. Wn calls of cv::cuda::warpPerspective(frame, warped[w], M[w], size) with INTER_LINEAR / BORDER_CONSTANT 0.
+ *   h_forward   host doubles [Wn][9], row-major 3x3 forward homographies K*R*K^-1 exactly as image.cpp:106 stores them
+ *               (nmi_warp_homographies builds them from K and the warp axes of a grid);
+ *   d_frame     device uint8 [H][W]; d_warp_stack device uint8 [Wn][H][W], w = (wZ*nWy + wY)*nWx + wX.
+ * Enqueued on the context's stream (no synchronisation).  OpenCV is not part of the reference tree: parity of the
+ * interpolation arithmetic is unpinned (see the kernel comment).
+ */
+int nmi_warp_homographies(const double K[9], const int32_t num_warp_xyz[3], const float step_rad_xyz[3],
+                          double *h_forward /*[Wn][9]*/);
+int nmi_warp_stack(nmi_ctx *ctx, const uint8_t *d_frame, const double *h_forward, int32_t Wn, uint8_t *d_warp_stack);
 
 /* Packed-key helpers (host side, pure). */
 uint64_t nmi_key_pack(float score, int64_t global_linear_index);

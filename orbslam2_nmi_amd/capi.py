@@ -22,8 +22,8 @@ ERR_NOT_READY = -4
 
 # Every symbol include/nmi_hip.h declares; tests check that the library exports all of them.
 EXPORTED_SYMBOLS = (
-    "nmi_params_default", "nmi_create", "nmi_destroy", "nmi_set_stream", "nmi_eval_pair", "nmi_eval_pair_debug",
-    "nmi_search_grid", "nmi_search_grid_shard", "nmi_key_pack", "nmi_key_unpack", "nmi_search_grid_rccl",
+    "nmi_params_default", "nmi_create", "nmi_destroy", "nmi_set_stream", "nmi_synchronize", "nmi_eval_pair", "nmi_eval_pair_debug",
+    "nmi_search_grid", "nmi_search_grid_shard", "nmi_warp_homographies", "nmi_warp_stack", "nmi_key_pack", "nmi_key_unpack", "nmi_search_grid_rccl",
     "nmi_rccl_unique_id", "nmi_rccl_comm_init", "nmi_rccl_comm_destroy", "nmi_set_profiling", "nmi_last_kernel_ms",
     "nmi_set_option", "nmi_abi_version", "nmi_error_string", "nmi_last_error_detail", "nmi_get_info",
 )
@@ -67,10 +67,13 @@ def load_library(build_if_missing=False):
     lib.nmi_create.argtypes = [C.POINTER(NmiParams), C.POINTER(vp)]
     lib.nmi_destroy.argtypes = [vp]
     lib.nmi_set_stream.argtypes = [vp, vp]
+    lib.nmi_synchronize.argtypes = [vp]
     lib.nmi_eval_pair.argtypes = [vp, vp, vp, f32p]
     lib.nmi_eval_pair_debug.argtypes = [vp, vp, vp, f32p, vp, vp, vp, vp]
     lib.nmi_search_grid.argtypes = [vp, vp, i32, vp, i32, vp, i64p, f32p]
     lib.nmi_search_grid_shard.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp, u64p]
+    lib.nmi_warp_homographies.argtypes = [C.POINTER(C.c_double), C.POINTER(i32), f32p, C.POINTER(C.c_double)]
+    lib.nmi_warp_stack.argtypes = [vp, vp, C.POINTER(C.c_double), i32, vp]
     lib.nmi_key_pack.argtypes = [C.c_float, C.c_int64]
     lib.nmi_key_pack.restype = C.c_uint64
     lib.nmi_key_unpack.argtypes = [C.c_uint64, i64p, f32p]
@@ -102,6 +105,20 @@ def key_unpack(key):
     idx, sc = C.c_int64(0), C.c_float(0)
     load_library().nmi_key_unpack(C.c_uint64(int(key) & 0xFFFFFFFFFFFFFFFF), C.byref(idx), C.byref(sc))
     return int(idx.value), np.float32(sc.value)
+
+
+def warp_homographies(K, num_warp_xyz, step_rad_xyz):
+    """K*Rz*Ry*Rx*K^-1 per warp cell (image.cpp:76-107) -> float64 [Wn, 3, 3], w = (wz*ny + wy)*nx + wx."""
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    num = (C.c_int32 * 3)(*[int(n) for n in num_warp_xyz])
+    step = (C.c_float * 3)(*[float(s) for s in step_rad_xyz])
+    wn = int(np.prod([int(n) for n in num_warp_xyz]))
+    out = np.zeros((wn, 3, 3), np.float64)
+    rc = load_library().nmi_warp_homographies(K.ctypes.data_as(C.POINTER(C.c_double)), num, step,
+                                              out.ctypes.data_as(C.POINTER(C.c_double)))
+    if rc != NMI_OK:
+        raise NmiError(rc, "nmi_warp_homographies")
+    return out
 
 
 def _dev_u8(t, ndim, what):
@@ -172,6 +189,9 @@ class NmiContext:
     def set_option(self, option, value):
         self._check(self._lib.nmi_set_option(self._h, int(option), int(value)), "nmi_set_option")
 
+    def synchronize(self):
+        self._check(self._lib.nmi_synchronize(self._h), "nmi_synchronize")
+
     def set_profiling(self, on):
         self._check(self._lib.nmi_set_profiling(self._h, int(bool(on))), "nmi_set_profiling")
 
@@ -219,6 +239,25 @@ class NmiContext:
                                                   h1.data_ptr(), h2.data_ptr(), sums.data_ptr()), "nmi_eval_pair_debug")
         u32 = lambda t: t.cpu().numpy().view(np.uint32)
         return np.float32(out.value), u32(joint).reshape(256, 256), u32(h1), u32(h2), sums.cpu().numpy()
+
+    def warp_stack(self, frame, homographies, out=None, sync=True):
+        """Image::calculateWarping (image.cpp:115-128) on the device: frame [H,W] u8 + forward homographies [Wn,3,3]
+        (float64, host) -> warp stack [Wn,H,W] u8 (device).  Enqueued on the context's stream."""
+        import torch
+        f = self._img(frame, "frame")
+        m = np.ascontiguousarray(homographies, np.float64).reshape(-1, 9)
+        wn = m.shape[0]
+        if out is None:
+            out = torch.empty((wn, self.height, self.width), dtype=torch.uint8, device=self.device)
+        o = self._stack(out, "out")
+        if o.shape[0] != wn:
+            raise ValueError("out has the wrong number of warps")
+        torch.cuda.current_stream(self.device).synchronize()  # `out` / `frame` may come from torch's stream
+        self._check(self._lib.nmi_warp_stack(self._h, f.data_ptr(), m.ctypes.data_as(C.POINTER(C.c_double)), wn,
+                                             o.data_ptr()), "nmi_warp_stack")
+        if sync:
+            self.synchronize()
+        return out
 
     def search_grid(self, render_stack, warp_stack, ratings=None):
         """Candidate loop + arg-max (Tracking.cc:1879-1905,1952).  -> (best linear index w*S+s, best score).

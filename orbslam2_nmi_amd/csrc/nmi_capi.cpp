@@ -6,6 +6,7 @@
 // host<->device traffic per search is one 8-byte key.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -36,6 +37,9 @@ struct nmi_ctx {
     int result_path = 1;                   // 1 mailbox spin (default), 0 hipMemcpyAsync + stream sync
     bool posted = false;                   // the most recent launch posts to the mailbox
     float *d_pair_rating = nullptr;
+    float *d_warp_coeffs = nullptr;       // [cap][9] inverse homographies for the warp producer
+    float *h_warp_coeffs = nullptr;       // pinned staging for them
+    int warp_coeffs_cap = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     int hist_variant = 3;
     int phase_mask = 3;
@@ -314,6 +318,8 @@ int nmi_destroy(nmi_ctx *ctx)
     if (ctx->d_done) (void)hipFree(ctx->d_done);
     if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
     if (ctx->d_pair_rating) (void)hipFree(ctx->d_pair_rating);
+    if (ctx->d_warp_coeffs) (void)hipFree(ctx->d_warp_coeffs);
+    if (ctx->h_warp_coeffs) (void)hipHostFree(ctx->h_warp_coeffs);
     if (ctx->h_key) (void)hipHostFree(ctx->h_key);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -326,6 +332,14 @@ int nmi_set_stream(nmi_ctx *ctx, void *stream)
 {
     if (!ctx) return NMI_ERR_INVALID_ARGUMENT;
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    return NMI_OK;
+}
+
+int nmi_synchronize(nmi_ctx *ctx)
+{
+    if (!ctx) return NMI_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(ctx->device);
+    NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return NMI_OK;
 }
 
@@ -378,6 +392,75 @@ int nmi_get_info(nmi_ctx *ctx, int32_t *compute_units, int32_t *workgroups_per_l
     if (compute_units) *compute_units = ctx->compute_units;
     if (workgroups_per_launch) *workgroups_per_launch = ctx->compute_units;
     if (lds_bytes) *lds_bytes = nmi::grid_kernel_lds_bytes();
+    return NMI_OK;
+}
+
+// Image::Image warp matrices, image.cpp:76-107: theta_a starts at -(n_a - 1)/2 * step_a with the integer division
+// of the reference, advances by step_a; R = Rz*Ry*Rx; M = K * R * K^-1 (doubles).
+int nmi_warp_homographies(const double K[9], const int32_t num[3], const float step[3], double *out)
+{
+    if (!K || !num || !step || !out || num[0] <= 0 || num[1] <= 0 || num[2] <= 0) return NMI_ERR_INVALID_ARGUMENT;
+    const double det = K[0] * (K[4] * K[8] - K[5] * K[7]) - K[1] * (K[3] * K[8] - K[5] * K[6]) + K[2] * (K[3] * K[7] - K[4] * K[6]);
+    if (det == 0.0) return NMI_ERR_INVALID_ARGUMENT;
+    double Ki[9] = {(K[4] * K[8] - K[5] * K[7]) / det, (K[2] * K[7] - K[1] * K[8]) / det, (K[1] * K[5] - K[2] * K[4]) / det,
+                    (K[5] * K[6] - K[3] * K[8]) / det, (K[0] * K[8] - K[2] * K[6]) / det, (K[2] * K[3] - K[0] * K[5]) / det,
+                    (K[3] * K[7] - K[4] * K[6]) / det, (K[1] * K[6] - K[0] * K[7]) / det, (K[0] * K[4] - K[1] * K[3]) / det};
+    auto mul3 = [](const double *a, const double *b, double *c) {
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) c[i * 3 + j] = a[i * 3] * b[j] + a[i * 3 + 1] * b[3 + j] + a[i * 3 + 2] * b[6 + j];
+    };
+    const int nx = num[0], ny = num[1], nz = num[2];
+    double tz = (double)((float)(-(nz - 1) / 2) * step[2]);
+    for (int i = 0; i < nz; ++i, tz += step[2]) {
+        const double Rz[9] = {cos(tz), -sin(tz), 0, sin(tz), cos(tz), 0, 0, 0, 1};
+        double ty = (double)((float)(-(ny - 1) / 2) * step[1]);
+        for (int j = 0; j < ny; ++j, ty += step[1]) {
+            const double Ry[9] = {cos(ty), 0, sin(ty), 0, 1, 0, -sin(ty), 0, cos(ty)};
+            double tx = (double)((float)(-(nx - 1) / 2) * step[0]);
+            for (int k = 0; k < nx; ++k, tx += step[0]) {
+                const double Rx[9] = {1, 0, 0, 0, cos(tx), -sin(tx), 0, sin(tx), cos(tx)};
+                double t1[9], R[9], t2[9];
+                mul3(Rz, Ry, t1);
+                mul3(t1, Rx, R);
+                mul3(K, R, t2);
+                mul3(t2, Ki, out + ((size_t)(i * ny + j) * nx + k) * 9);
+            }
+        }
+    }
+    return NMI_OK;
+}
+
+int nmi_warp_stack(nmi_ctx *ctx, const uint8_t *d_frame, const double *h_forward, int32_t Wn, uint8_t *d_warp_stack)
+{
+    if (!ctx || !d_frame || !h_forward || !d_warp_stack || Wn <= 0) return NMI_ERR_INVALID_ARGUMENT;
+    ctx->detail.clear();
+    DeviceGuard guard(ctx->device);
+    if (Wn > ctx->warp_coeffs_cap) {
+        if (ctx->d_warp_coeffs) NMI_HIP_TRY(ctx, hipFree(ctx->d_warp_coeffs));
+        if (ctx->h_warp_coeffs) NMI_HIP_TRY(ctx, hipHostFree(ctx->h_warp_coeffs));
+        ctx->d_warp_coeffs = ctx->h_warp_coeffs = nullptr;
+        ctx->warp_coeffs_cap = 0;
+        NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_warp_coeffs, (size_t)Wn * 9 * sizeof(float)));
+        NMI_HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_warp_coeffs, (size_t)Wn * 9 * sizeof(float), hipHostMallocDefault));
+        ctx->warp_coeffs_cap = Wn;
+    } else {
+        // the staging buffer may still feed an earlier, unfinished copy on this stream
+        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    // warpPerspective inverts the forward matrix on the host in double and hands 9 floats to the device
+    for (int w = 0; w < Wn; ++w) {
+        const double *m = h_forward + (size_t)w * 9;
+        const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+        if (det == 0.0) return NMI_ERR_INVALID_ARGUMENT;
+        const double inv[9] = {(m[4] * m[8] - m[5] * m[7]) / det, (m[2] * m[7] - m[1] * m[8]) / det, (m[1] * m[5] - m[2] * m[4]) / det,
+                               (m[5] * m[6] - m[3] * m[8]) / det, (m[0] * m[8] - m[2] * m[6]) / det, (m[2] * m[3] - m[0] * m[5]) / det,
+                               (m[3] * m[7] - m[4] * m[6]) / det, (m[1] * m[6] - m[0] * m[7]) / det, (m[0] * m[4] - m[1] * m[3]) / det};
+        for (int e = 0; e < 9; ++e) ctx->h_warp_coeffs[w * 9 + e] = (float)inv[e];
+    }
+    NMI_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_warp_coeffs, ctx->h_warp_coeffs, (size_t)Wn * 9 * sizeof(float), hipMemcpyHostToDevice,
+                                    ctx->stream));
+    NMI_HIP_TRY(ctx, nmi::launch_warp(d_frame, ctx->d_warp_coeffs, d_warp_stack, ctx->params.width, ctx->params.height, Wn,
+                                      ctx->stream));
     return NMI_OK;
 }
 

@@ -45,5 +45,7 @@ struct GridArgs {
 hipError_t launch_table(float *table, int npix, hipStream_t stream);
 hipError_t launch_grid(const GridArgs &a, int workgroups, bool use_bg, hipStream_t stream);
 int grid_kernel_lds_bytes();
+hipError_t launch_warp(const uint8_t *frame, const float *coeffs /*[Wn][9] inverse maps*/, uint8_t *out, int width,
+                       int height, int Wn, hipStream_t stream);
 
 }  // namespace nmi

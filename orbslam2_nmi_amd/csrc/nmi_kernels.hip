@@ -584,4 +584,69 @@ hipError_t launch_grid(const GridArgs &a, int workgroups, bool use_bg, hipStream
 
 int grid_kernel_lds_bytes() { return (int)sizeof(Lds); }
 
+// ---------------------------------------------------------------------------------------------------------
+// Warp-stack producer: Image::calculateWarping, Thirdparty/Localization/image.cpp:115-128 --
+// Wn calls of cv::cuda::warpPerspective(frame, warped[w], K*R*K^-1, size) with the defaults INTER_LINEAR,
+// BORDER_CONSTANT(0), forward matrix.  OpenCV 3.4.0 is not vendored in the reference and absent here, so the
+// arithmetic below follows OpenCV's published device path (inverse matrix as 9 floats; source coordinate
+// (c0*x+c1*y+c2)/(c6*x+c7*y+c8) in fp32; bilinear LinearFilter with floor(), the four taps accumulated in the
+// order (y1,x1) (y1,x2) (y2,x1) (y2,x2); saturate_cast<uchar> = round to nearest even) -- parity unpinned.
+// One thread produces 4 horizontally adjacent pixels of one warp and stores them as one dword.
+__device__ __forceinline__ float warp_tap(const uint8_t *__restrict__ src, int w, int h, int x, int y)
+{
+    return (x >= 0 && x < w && y >= 0 && y < h) ? (float)src[y * w + x] : 0.0f;  // BORDER_CONSTANT, value 0
+}
+
+__global__ __launch_bounds__(256) void nmi_warp_kernel(const uint8_t *__restrict__ frame, const float *__restrict__ coeffs,
+                                                       uint8_t *__restrict__ out, int width, int height, int quads_per_row)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int wi = blockIdx.z;
+    if (q >= quads_per_row) return;
+    const float *c = coeffs + wi * 9;
+    uint32_t packed = 0;
+    uint8_t px[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = q * 4 + k;
+        uint32_t v = 0;
+        if (x < width) {
+            const float fx = (float)x, fy = (float)y;
+            const float den = c[6] * fx + c[7] * fy + c[8];
+            const float xs = (c[0] * fx + c[1] * fy + c[2]) / den;
+            const float ys = (c[3] * fx + c[4] * fy + c[5]) / den;
+            // coordinates far outside the frame (or non-finite) see only the constant border
+            float acc = 0.0f;
+            if (xs > -2.0f && xs < (float)(width + 1) && ys > -2.0f && ys < (float)(height + 1)) {
+                const int x1 = (int)floorf(xs), y1 = (int)floorf(ys);
+                const int x2 = x1 + 1, y2 = y1 + 1;
+                acc = acc + warp_tap(frame, width, height, x1, y1) * (((float)x2 - xs) * ((float)y2 - ys));
+                acc = acc + warp_tap(frame, width, height, x2, y1) * ((xs - (float)x1) * ((float)y2 - ys));
+                acc = acc + warp_tap(frame, width, height, x1, y2) * (((float)x2 - xs) * (ys - (float)y1));
+                acc = acc + warp_tap(frame, width, height, x2, y2) * ((xs - (float)x1) * (ys - (float)y1));
+            }
+            const float r = rintf(acc);
+            v = r <= 0.0f ? 0u : (r >= 255.0f ? 255u : (uint32_t)r);
+        }
+        px[k] = (uint8_t)v;
+        packed |= v << (8 * k);
+    }
+    uint8_t *dst = out + ((size_t)wi * height + y) * width + q * 4;
+    if ((width & 3) == 0 && ((uintptr_t)out & 3) == 0) {
+        *reinterpret_cast<uint32_t *>(dst) = packed;
+    } else {
+        for (int k = 0; k < 4 && q * 4 + k < width; ++k) dst[k] = px[k];
+    }
+}
+
+hipError_t launch_warp(const uint8_t *frame, const float *coeffs, uint8_t *out, int width, int height, int Wn,
+                       hipStream_t stream)
+{
+    const int quads = (width + 3) / 4;
+    dim3 block(256), grid((quads + 255) / 256, height, Wn);
+    hipLaunchKernelGGL(nmi_warp_kernel, grid, block, 0, stream, frame, coeffs, out, width, height, quads);
+    return hipGetLastError();
+}
+
 }  // namespace nmi

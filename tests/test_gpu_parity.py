@@ -190,6 +190,58 @@ def test_grid_config2_729_candidates(nmi):
     assert idx == wl["planted"] == 364
 
 
+def test_grid_config3_shape_4096_candidates(nmi):
+    """BASELINE.json config 3: 960x540 (ZU-MAV half resolution), 64 renders x 64 warps = 4096 candidates."""
+    from orbslam2_nmi_amd import synthetic as sy
+    wl = sy.workload(960, 540, 64, 64, seed=77)
+    idx, best, r = grid_vs_oracle(nmi, wl, 960, 540)
+    assert idx == wl["planted"]
+    assert r.shape == (64, 64)
+
+
+def test_grid_config4_shard_shape(nmi):
+    """BASELINE.json config 4, one rank's share: 848x480 (Newer College), 64 of 512 renders x 64 warps, global indices."""
+    from oracle import binding as oc
+    from orbslam2_nmi_amd import synthetic as sy
+    wl = sy.workload(848, 480, 64, 64, seed=5)
+    rs, ws = wl["render_stack"], wl["warp_stack"]
+    rank, s_total = 3, 512
+    with nmi.NmiContext(848, 480) as ctx:
+        t = torch.zeros(64, 64, device="cuda")
+        key = ctx.search_grid_shard(dev(rs), 64 * rank, s_total, dev(ws), t)
+    ro, io, bo = oc.search_grid(rs, ws, threads=16)
+    assert np.abs(t.cpu().numpy() - ro).max() <= SCORE_TOL
+    w, s = divmod(io, 64)
+    assert nmi.key_unpack(key) == (w * s_total + 64 * rank + s, bo)
+
+
+def test_full_size_properties_without_oracle(nmi):
+    """Size-independent properties at full size (no oracle): permutation invariance of the histogram under a common
+    pixel permutation, symmetry of SUC in its two images, identical pair -> 1, and arg-max consistency."""
+    rng = np.random.default_rng(123)
+    w, h = 960, 540
+    a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    b = np.clip(a.astype(int) + rng.integers(-30, 30, (h, w)), 0, 255).astype(np.uint8)
+    perm = rng.permutation(h * w)
+    with nmi.NmiContext(w, h, render_bottom_up=False) as ctx:
+        s_ab, j_ab, h1, h2, _ = ctx.eval_pair_debug(dev(a), dev(b))
+        s_ba, j_ba, _, _, _ = ctx.eval_pair_debug(dev(b), dev(a))
+        s_pp, j_pp, _, _, _ = ctx.eval_pair_debug(dev(a.reshape(-1)[perm].reshape(h, w)), dev(b.reshape(-1)[perm].reshape(h, w)))
+        assert (j_ab == j_ba.T).all() and (j_ab == j_pp).all()
+        assert j_ab.sum() == h * w and (j_ab.sum(1) == h1).all() and (j_ab.sum(0) == h2).all()
+        assert (h1 == np.bincount(a.reshape(-1), minlength=256)).all()
+        assert s_pp == s_ab and abs(float(s_ab) - float(s_ba)) <= 1e-6
+        assert ctx.eval_pair(dev(b), dev(b)) == np.float32(1.0)
+        # a grid whose table is known by construction: renders = {b, a, b}, warps = {a, b}
+        rs = torch.stack([dev(b), dev(a), dev(b)])
+        ws = torch.stack([dev(a), dev(b)])
+        t = torch.zeros(2, 3, device="cuda")
+        idx, best = ctx.search_grid(rs, ws, t)
+        tt = t.cpu().numpy()
+        assert best == np.float32(1.0) and idx == 0 * 3 + 1            # (w=0:a, s=1:a) is the first identical pair
+        assert tt[0, 1] == 1.0 and tt[1, 0] == 1.0 and tt[1, 2] == 1.0 and tt[0, 0] == s_ba and tt[1, 1] == s_ab
+
+
 def test_grid_switches_and_ties(nmi):
     from orbslam2_nmi_amd import synthetic as sy
     wl = sy.workload(160, 120, 8, 12, seed=5, bottom_up=False)
