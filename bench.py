@@ -64,8 +64,66 @@ def load_pmc_traffic():
         return None
 
 
+def run_stream_config(args):
+    """BASELINE.json config 5 on the local GPU: 100-keyframe synthetic sequence, 3 search levels per keyframe (steps halved
+    per level like NmiSearchKernel::resizeKernel), 3^6 candidates per level at 848x480, render stacks streamed from pinned
+    host memory through the double-buffered pipeline (nmi_stream_*), warp stacks produced on the device per level.
+    Not the headline line: prints its own JSON (keyframes/s and evals/s, H2D included)."""
+    import torch
+
+    import orbslam2_nmi_amd as nmi
+    from orbslam2_nmi_amd import capi, synthetic as sy
+
+    w, h, counts, levels, pool = 848, 480, (3, 3, 3), 3, 4
+    K = sy.intrinsics(w, h)
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    frames, stacks, homs, planted = [], [], [], []
+    for kf in range(pool):
+        B = sy.scene(w, h, 9000 + kf)
+        frames.append(torch.from_numpy(sy.camera_frame(B, 9500 + kf)).pin_memory())
+        for lvl in range(levels):
+            stacks.append(torch.from_numpy(sy.render_stack(B, counts, shift_px=max(1, 4 >> lvl), zoom_step=0.02 / 2 ** lvl)).pin_memory())
+            homs.append(capi.warp_homographies(K, counts, tuple(s / 2 ** lvl for s in (0.02, 0.02, 0.05))))
+    ctx = nmi.NmiContext(w, h, render_bottom_up=False)
+    st = nmi.NmiStream(ctx, 27, 27, depth=2)
+    n_kf = args.keyframes
+
+    def run(nk):
+        pending, winners = [], []
+        for i in range(nk * levels):
+            kf, lvl = (i // levels) % pool, i % levels
+            pending.append(st.submit(stacks[kf * levels + lvl], frames[kf], homs[kf * levels + lvl]))
+            if len(pending) == 2:
+                winners.append(st.wait(pending.pop(0)))
+        while pending:
+            winners.append(st.wait(pending.pop(0)))
+        return winners
+
+    run(4)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    winners = run(n_kf)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    centre = 13 * 27 + 13
+    if any(wn[0] != centre for wn in winners):
+        sys.exit(f"stream config: unexpected winners {sorted(set(x[0] for x in winners))}")
+    evals = n_kf * levels * 729
+    h2d = n_kf * levels * (27 + 1) * w * h
+    print(json.dumps({"metric": "keyframes/s (config 5: 848x480, 3 levels x 729 candidates, render stacks streamed H2D)",
+                      "value": n_kf / dt, "unit": "keyframes/s", "evals_per_s": evals / dt, "n_gpus": 1,
+                      "keyframes": n_kf, "levels": levels, "h2d_GBps": h2d / dt / 1e9, "data": "synthetic",
+                      "config": {"workload": "BASELINE.json configs[4] on one GPU", "width": w, "height": h,
+                                 "pipeline_depth": 2}}))
+    st.close()
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="c2", choices=["c2", "stream"],
+                    help="c2 = BASELINE.json configs[1] (the headline line); stream = configs[4] shape on the local GPU")
+    ap.add_argument("--keyframes", type=int, default=100)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
@@ -73,6 +131,8 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--cpu-threads", type=int, default=16, help="cap on oracle threads for the cpu_baseline leg")
     args = ap.parse_args()
+    if args.config == "stream":
+        return run_stream_config(args)
 
     import torch
 

@@ -142,6 +142,24 @@ int nmi_warp_homographies(const double K[9], const int32_t num_warp_xyz[3], cons
                           double *h_forward /*[Wn][9]*/);
 int nmi_warp_stack(nmi_ctx *ctx, const uint8_t *d_frame, const double *h_forward, int32_t Wn, uint8_t *d_warp_stack);
 
+/*
+ * Streaming form (BASELINE.json config 5): keyframes / search levels whose render stacks arrive from host memory.
+ * A stream owns `depth` device slots; nmi_stream_submit enqueues, without blocking,
+ *   copy stream    : hipMemcpyAsync of the pinned host render stack [S][H][W] (and the frame [H][W], if given) into a slot
+ *   compute stream : (frame given) warp-stack production for h_forward [Wn][9]; the grid kernel; 8-byte winner -> pinned host
+ * so the H2D copy of level i+1 overlaps the search of level i (the reference uploads and searches serially,
+ * src/Tracking.cc:1871-1902).  Tickets complete in submission order.  nmi_stream_wait blocks on one ticket.
+ * A slot is reused by submission i + depth only after ticket i was waited for.  h_* buffers must stay valid (and should be
+ * page-locked, e.g. hipHostMalloc) until the ticket completes.  Passing h_frame == NULL re-uses the warp stack produced by
+ * the most recent submission that had a frame.
+ */
+typedef struct nmi_stream nmi_stream;
+int nmi_stream_create(nmi_ctx *ctx, int32_t max_S, int32_t max_Wn, int32_t depth, nmi_stream **out);
+int nmi_stream_destroy(nmi_stream *st);
+int nmi_stream_submit(nmi_stream *st, const uint8_t *h_render_stack, int32_t S, const uint8_t *h_frame,
+                      const double *h_forward, int32_t Wn, int64_t *ticket);
+int nmi_stream_wait(nmi_stream *st, int64_t ticket, int64_t *h_best_index, float *h_best_score);
+
 /* Packed-key helpers (host side, pure). */
 uint64_t nmi_key_pack(float score, int64_t global_linear_index);
 int nmi_key_unpack(uint64_t key, int64_t *global_linear_index, float *score);

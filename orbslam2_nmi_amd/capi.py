@@ -23,7 +23,8 @@ ERR_NOT_READY = -4
 # Every symbol include/nmi_hip.h declares; tests check that the library exports all of them.
 EXPORTED_SYMBOLS = (
     "nmi_params_default", "nmi_create", "nmi_destroy", "nmi_set_stream", "nmi_synchronize", "nmi_eval_pair", "nmi_eval_pair_debug",
-    "nmi_search_grid", "nmi_search_grid_shard", "nmi_warp_homographies", "nmi_warp_stack", "nmi_key_pack", "nmi_key_unpack", "nmi_search_grid_rccl",
+    "nmi_search_grid", "nmi_search_grid_shard", "nmi_warp_homographies", "nmi_warp_stack", "nmi_stream_create", "nmi_stream_destroy",
+    "nmi_stream_submit", "nmi_stream_wait", "nmi_key_pack", "nmi_key_unpack", "nmi_search_grid_rccl",
     "nmi_rccl_unique_id", "nmi_rccl_comm_init", "nmi_rccl_comm_destroy", "nmi_set_profiling", "nmi_last_kernel_ms",
     "nmi_set_option", "nmi_abi_version", "nmi_error_string", "nmi_last_error_detail", "nmi_get_info",
 )
@@ -74,6 +75,10 @@ def load_library(build_if_missing=False):
     lib.nmi_search_grid_shard.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp, u64p]
     lib.nmi_warp_homographies.argtypes = [C.POINTER(C.c_double), C.POINTER(i32), f32p, C.POINTER(C.c_double)]
     lib.nmi_warp_stack.argtypes = [vp, vp, C.POINTER(C.c_double), i32, vp]
+    lib.nmi_stream_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    lib.nmi_stream_destroy.argtypes = [vp]
+    lib.nmi_stream_submit.argtypes = [vp, vp, i32, vp, C.POINTER(C.c_double), i32, i64p]
+    lib.nmi_stream_wait.argtypes = [vp, C.c_int64, i64p, f32p]
     lib.nmi_key_pack.argtypes = [C.c_float, C.c_int64]
     lib.nmi_key_pack.restype = C.c_uint64
     lib.nmi_key_unpack.argtypes = [C.c_uint64, i64p, f32p]
@@ -313,6 +318,50 @@ class NmiContext:
                                                    Wn, self._ratings_ptr(ratings, Wn, S), comm, C.byref(idx),
                                                    C.byref(sc)), "nmi_search_grid_rccl")
         return int(idx.value), np.float32(sc.value)
+
+
+class NmiStream:
+    """nmi_stream wrapper: double-buffered keyframe pipeline (H2D of render stacks beside the search)."""
+
+    def __init__(self, ctx, max_S, max_Wn, depth=2):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        self._h = C.c_void_p()
+        ctx._check(self._lib.nmi_stream_create(ctx._h, int(max_S), int(max_Wn), int(depth), C.byref(self._h)),
+                   "nmi_stream_create")
+        self._keep = {}
+
+    def submit(self, render_stack_host, frame_host=None, homographies=None):
+        """render_stack_host / frame_host: pinned CPU uint8 torch tensors; homographies: float64 [Wn,3,3] (with a frame)."""
+        rs = render_stack_host
+        if rs.is_cuda or rs.dtype.__str__() != "torch.uint8" or not rs.is_contiguous():
+            raise TypeError("render_stack_host must be a contiguous CPU uint8 tensor (pinned for overlap)")
+        fp, mp, wn, m = None, None, 0, None
+        if frame_host is not None:
+            m = np.ascontiguousarray(homographies, np.float64).reshape(-1, 9)
+            fp, mp, wn = frame_host.data_ptr(), m.ctypes.data_as(C.POINTER(C.c_double)), m.shape[0]
+        t = C.c_int64(-1)
+        self.ctx._check(self._lib.nmi_stream_submit(self._h, rs.data_ptr(), rs.shape[0], fp, mp, wn, C.byref(t)),
+                        "nmi_stream_submit")
+        self._keep[t.value] = (rs, frame_host, m)  # keep host buffers alive until the ticket completes
+        return int(t.value)
+
+    def wait(self, ticket):
+        idx, sc = C.c_int64(0), C.c_float(0)
+        self.ctx._check(self._lib.nmi_stream_wait(self._h, int(ticket), C.byref(idx), C.byref(sc)), "nmi_stream_wait")
+        self._keep.pop(ticket, None)
+        return int(idx.value), np.float32(sc.value)
+
+    def close(self):
+        if self._h and self._h.value:
+            self._lib.nmi_stream_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 def rccl_unique_id():

@@ -37,9 +37,14 @@ struct nmi_ctx {
     int result_path = 1;                   // 1 mailbox spin (default), 0 hipMemcpyAsync + stream sync
     bool posted = false;                   // the most recent launch posts to the mailbox
     float *d_pair_rating = nullptr;
-    float *d_warp_coeffs = nullptr;       // [cap][9] inverse homographies for the warp producer
-    float *h_warp_coeffs = nullptr;       // pinned staging for them
+    // inverse homographies for the warp producer: a small ring of (pinned staging, device copy, "copy consumed" event)
+    // so that back-to-back submissions never wait for the stream
+    static constexpr int kWarpRing = 4;
+    float *d_warp_coeffs[kWarpRing] = {};
+    float *h_warp_coeffs[kWarpRing] = {};
+    hipEvent_t warp_ev[kWarpRing] = {};
     int warp_coeffs_cap = 0;
+    unsigned warp_uses = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     int hist_variant = 3;
     int phase_mask = 3;
@@ -318,8 +323,11 @@ int nmi_destroy(nmi_ctx *ctx)
     if (ctx->d_done) (void)hipFree(ctx->d_done);
     if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
     if (ctx->d_pair_rating) (void)hipFree(ctx->d_pair_rating);
-    if (ctx->d_warp_coeffs) (void)hipFree(ctx->d_warp_coeffs);
-    if (ctx->h_warp_coeffs) (void)hipHostFree(ctx->h_warp_coeffs);
+    for (int i = 0; i < nmi_ctx::kWarpRing; ++i) {
+        if (ctx->d_warp_coeffs[i]) (void)hipFree(ctx->d_warp_coeffs[i]);
+        if (ctx->h_warp_coeffs[i]) (void)hipHostFree(ctx->h_warp_coeffs[i]);
+        if (ctx->warp_ev[i]) (void)hipEventDestroy(ctx->warp_ev[i]);
+    }
     if (ctx->h_key) (void)hipHostFree(ctx->h_key);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -436,17 +444,24 @@ int nmi_warp_stack(nmi_ctx *ctx, const uint8_t *d_frame, const double *h_forward
     ctx->detail.clear();
     DeviceGuard guard(ctx->device);
     if (Wn > ctx->warp_coeffs_cap) {
-        if (ctx->d_warp_coeffs) NMI_HIP_TRY(ctx, hipFree(ctx->d_warp_coeffs));
-        if (ctx->h_warp_coeffs) NMI_HIP_TRY(ctx, hipHostFree(ctx->h_warp_coeffs));
-        ctx->d_warp_coeffs = ctx->h_warp_coeffs = nullptr;
-        ctx->warp_coeffs_cap = 0;
-        NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_warp_coeffs, (size_t)Wn * 9 * sizeof(float)));
-        NMI_HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_warp_coeffs, (size_t)Wn * 9 * sizeof(float), hipHostMallocDefault));
-        ctx->warp_coeffs_cap = Wn;
-    } else {
-        // the staging buffer may still feed an earlier, unfinished copy on this stream
         NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < nmi_ctx::kWarpRing; ++i) {
+            if (ctx->d_warp_coeffs[i]) NMI_HIP_TRY(ctx, hipFree(ctx->d_warp_coeffs[i]));
+            if (ctx->h_warp_coeffs[i]) NMI_HIP_TRY(ctx, hipHostFree(ctx->h_warp_coeffs[i]));
+            ctx->d_warp_coeffs[i] = ctx->h_warp_coeffs[i] = nullptr;
+        }
+        ctx->warp_coeffs_cap = 0;
+        for (int i = 0; i < nmi_ctx::kWarpRing; ++i) {
+            NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_warp_coeffs[i], (size_t)Wn * 9 * sizeof(float)));
+            NMI_HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_warp_coeffs[i], (size_t)Wn * 9 * sizeof(float), hipHostMallocDefault));
+            if (!ctx->warp_ev[i]) NMI_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->warp_ev[i], hipEventDisableTiming));
+        }
+        ctx->warp_coeffs_cap = Wn;
     }
+    const int ring = (int)(ctx->warp_uses++ % nmi_ctx::kWarpRing);
+    // this ring entry was last used kWarpRing submissions ago; normally long finished
+    NMI_HIP_TRY(ctx, hipEventSynchronize(ctx->warp_ev[ring]));
+    float *h_coeffs = ctx->h_warp_coeffs[ring], *d_coeffs = ctx->d_warp_coeffs[ring];
     // warpPerspective inverts the forward matrix on the host in double and hands 9 floats to the device
     for (int w = 0; w < Wn; ++w) {
         const double *m = h_forward + (size_t)w * 9;
@@ -455,13 +470,167 @@ int nmi_warp_stack(nmi_ctx *ctx, const uint8_t *d_frame, const double *h_forward
         const double inv[9] = {(m[4] * m[8] - m[5] * m[7]) / det, (m[2] * m[7] - m[1] * m[8]) / det, (m[1] * m[5] - m[2] * m[4]) / det,
                                (m[5] * m[6] - m[3] * m[8]) / det, (m[0] * m[8] - m[2] * m[6]) / det, (m[2] * m[3] - m[0] * m[5]) / det,
                                (m[3] * m[7] - m[4] * m[6]) / det, (m[1] * m[6] - m[0] * m[7]) / det, (m[0] * m[4] - m[1] * m[3]) / det};
-        for (int e = 0; e < 9; ++e) ctx->h_warp_coeffs[w * 9 + e] = (float)inv[e];
+        for (int e = 0; e < 9; ++e) h_coeffs[w * 9 + e] = (float)inv[e];
     }
-    NMI_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_warp_coeffs, ctx->h_warp_coeffs, (size_t)Wn * 9 * sizeof(float), hipMemcpyHostToDevice,
-                                    ctx->stream));
-    NMI_HIP_TRY(ctx, nmi::launch_warp(d_frame, ctx->d_warp_coeffs, d_warp_stack, ctx->params.width, ctx->params.height, Wn,
-                                      ctx->stream));
+    NMI_HIP_TRY(ctx, hipMemcpyAsync(d_coeffs, h_coeffs, (size_t)Wn * 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    NMI_HIP_TRY(ctx, nmi::launch_warp(d_frame, d_coeffs, d_warp_stack, ctx->params.width, ctx->params.height, Wn, ctx->stream));
+    NMI_HIP_TRY(ctx, hipEventRecord(ctx->warp_ev[ring], ctx->stream));
     return NMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Streaming pipeline (config 5): double-buffered render stacks, copy stream beside the compute stream.
+// ---------------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+struct nmi_stream {
+    nmi_ctx *ctx = nullptr;
+    int depth = 0, max_S = 0, max_Wn = 0;
+    hipStream_t copy = nullptr;
+    struct Slot {
+        uint8_t *d_renders = nullptr;
+        unsigned long long *d_key = nullptr;
+        unsigned long long *h_key = nullptr;
+        hipEvent_t copied = nullptr, done = nullptr;
+        int64_t ticket = -1;
+        bool waited = true;
+    };
+    Slot *slots = nullptr;
+    uint8_t *d_frame[2] = {nullptr, nullptr};  // frames alternate so an upload never overwrites one still being warped
+    uint8_t *d_warps[2] = {nullptr, nullptr};
+    hipEvent_t frame_copied = nullptr, warps_free[2] = {nullptr, nullptr};
+    int warp_buf = 0;      // buffer holding the current warp stack
+    int cur_Wn = 0;
+    bool have_warps = false;
+    int64_t next_ticket = 0;
+};
+
+extern "C" {
+
+int nmi_stream_destroy(nmi_stream *st)
+{
+    if (!st) return NMI_OK;
+    DeviceGuard guard(st->ctx->device);
+    (void)hipStreamSynchronize(st->ctx->stream);
+    if (st->copy) (void)hipStreamSynchronize(st->copy);
+    for (int i = 0; st->slots && i < st->depth; ++i) {
+        nmi_stream::Slot &s = st->slots[i];
+        if (s.d_renders) (void)hipFree(s.d_renders);
+        if (s.d_key) (void)hipFree(s.d_key);
+        if (s.h_key) (void)hipHostFree(s.h_key);
+        if (s.copied) (void)hipEventDestroy(s.copied);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    delete[] st->slots;
+    for (int b = 0; b < 2; ++b) {
+        if (st->d_frame[b]) (void)hipFree(st->d_frame[b]);
+        if (st->d_warps[b]) (void)hipFree(st->d_warps[b]);
+        if (st->warps_free[b]) (void)hipEventDestroy(st->warps_free[b]);
+    }
+    if (st->frame_copied) (void)hipEventDestroy(st->frame_copied);
+    if (st->copy) (void)hipStreamDestroy(st->copy);
+    delete st;
+    return NMI_OK;
+}
+
+int nmi_stream_create(nmi_ctx *ctx, int32_t max_S, int32_t max_Wn, int32_t depth, nmi_stream **out)
+{
+    if (!ctx || !out || max_S <= 0 || max_Wn <= 0 || depth < 2 || depth > 64) return NMI_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    DeviceGuard guard(ctx->device);
+    nmi_stream *st = new (std::nothrow) nmi_stream;
+    if (!st) return NMI_ERR_INVALID_ARGUMENT;
+    st->ctx = ctx;
+    st->depth = depth;
+    st->max_S = max_S;
+    st->max_Wn = max_Wn;
+    st->slots = new (std::nothrow) nmi_stream::Slot[depth];
+    const size_t npix = (size_t)ctx->npix;
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t r) {
+        if (e == hipSuccess) e = r;
+        return r == hipSuccess;
+    };
+    ok(hipStreamCreateWithFlags(&st->copy, hipStreamNonBlocking));
+    for (int i = 0; st->slots && i < depth && e == hipSuccess; ++i) {
+        nmi_stream::Slot &s = st->slots[i];
+        ok(hipMalloc((void **)&s.d_renders, npix * max_S));
+        ok(hipMalloc((void **)&s.d_key, sizeof(unsigned long long)));
+        ok(hipHostMalloc((void **)&s.h_key, sizeof(unsigned long long), hipHostMallocDefault));
+        ok(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+        ok(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    }
+    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+        ok(hipMalloc((void **)&st->d_frame[b], npix));
+        ok(hipMalloc((void **)&st->d_warps[b], npix * max_Wn));
+        ok(hipEventCreateWithFlags(&st->warps_free[b], hipEventDisableTiming));
+    }
+    ok(hipEventCreateWithFlags(&st->frame_copied, hipEventDisableTiming));
+    if (!st->slots || e != hipSuccess) {
+        const int rc = st->slots ? hip_fail(ctx, e, "nmi_stream_create") : NMI_ERR_INVALID_ARGUMENT;
+        nmi_stream_destroy(st);
+        return rc;
+    }
+    *out = st;
+    return NMI_OK;
+}
+
+int nmi_stream_submit(nmi_stream *st, const uint8_t *h_render_stack, int32_t S, const uint8_t *h_frame,
+                      const double *h_forward, int32_t Wn, int64_t *ticket)
+{
+    if (!st || !h_render_stack || !ticket || S <= 0 || S > st->max_S) return NMI_ERR_INVALID_ARGUMENT;
+    if (h_frame && (!h_forward || Wn <= 0 || Wn > st->max_Wn)) return NMI_ERR_INVALID_ARGUMENT;
+    if (!h_frame && !st->have_warps) return NMI_ERR_INVALID_ARGUMENT;
+    nmi_ctx *ctx = st->ctx;
+    ctx->detail.clear();
+    DeviceGuard guard(ctx->device);
+    const int64_t t = st->next_ticket;
+    nmi_stream::Slot &s = st->slots[t % st->depth];
+    if (!s.waited) return NMI_ERR_NOT_READY;  // the ticket that used this slot has not been collected yet
+    const size_t npix = (size_t)ctx->npix;
+
+    // copy stream: render stack of this level into the slot (the slot's previous search finished: it was waited for)
+    NMI_HIP_TRY(ctx, hipMemcpyAsync(s.d_renders, h_render_stack, npix * S, hipMemcpyHostToDevice, st->copy));
+    if (h_frame) {
+        const int nb = st->have_warps ? st->warp_buf ^ 1 : 0;
+        // the buffer being refilled was last read by searches submitted before the previous frame switch
+        NMI_HIP_TRY(ctx, hipStreamWaitEvent(st->copy, st->warps_free[nb], 0));
+        NMI_HIP_TRY(ctx, hipMemcpyAsync(st->d_frame[nb], h_frame, npix, hipMemcpyHostToDevice, st->copy));
+        NMI_HIP_TRY(ctx, hipEventRecord(st->frame_copied, st->copy));
+        NMI_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, st->frame_copied, 0));
+        if (st->have_warps) NMI_HIP_TRY(ctx, hipEventRecord(st->warps_free[st->warp_buf], ctx->stream));
+        int rc = nmi_warp_stack(ctx, st->d_frame[nb], h_forward, Wn, st->d_warps[nb]);
+        if (rc != NMI_OK) return rc;
+        st->warp_buf = nb;
+        st->cur_Wn = Wn;
+        st->have_warps = true;
+    }
+    NMI_HIP_TRY(ctx, hipEventRecord(s.copied, st->copy));
+
+    // compute stream: search on the slot, winner to pinned host memory
+    NMI_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s.copied, 0));
+    int rc = enqueue_grid(ctx, s.d_renders, S, 0, S, st->d_warps[st->warp_buf], st->cur_Wn, nullptr, s.d_key, false, nullptr,
+                          nullptr, nullptr, nullptr);
+    if (rc != NMI_OK) return rc;
+    NMI_HIP_TRY(ctx, hipMemcpyAsync(s.h_key, s.d_key, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    NMI_HIP_TRY(ctx, hipEventRecord(s.done, ctx->stream));
+    s.ticket = t;
+    s.waited = false;
+    *ticket = t;
+    ++st->next_ticket;
+    return NMI_OK;
+}
+
+int nmi_stream_wait(nmi_stream *st, int64_t ticket, int64_t *h_best_index, float *h_best_score)
+{
+    if (!st || ticket < 0 || ticket >= st->next_ticket) return NMI_ERR_INVALID_ARGUMENT;
+    nmi_stream::Slot &s = st->slots[ticket % st->depth];
+    if (s.ticket != ticket || s.waited) return NMI_ERR_INVALID_ARGUMENT;  // overwritten or already collected
+    nmi_ctx *ctx = st->ctx;
+    DeviceGuard guard(ctx->device);
+    NMI_HIP_TRY(ctx, hipEventSynchronize(s.done));
+    s.waited = true;
+    return nmi_key_unpack(*s.h_key, h_best_index, h_best_score);
 }
 
 uint64_t nmi_key_pack(float score, int64_t global_linear_index)

@@ -332,3 +332,45 @@ def test_invalid_arguments_fail_loudly(nmi):
             ctx.eval_pair(torch.zeros(48, 32, dtype=torch.uint8, device="cuda"), torch.zeros(48, 32, dtype=torch.uint8, device="cuda"))
     with pytest.raises(nmi.NmiError):
         nmi.NmiContext(64, 48, bins=100)
+
+
+def test_streaming_pipeline_matches_sequential(nmi):
+    """BASELINE.json config 5 in small: keyframes x levels streamed from pinned host memory through the double-buffered
+    pipeline give the same winners as one blocking search per level on resident stacks."""
+    from orbslam2_nmi_amd import capi, synthetic as sy
+    w, h, S, counts = 160, 120, 8, (2, 2, 2)
+    K = sy.intrinsics(w, h)
+    levels = []
+    for kf in range(4):
+        B = sy.scene(w, h, 300 + kf)
+        F = sy.camera_frame(B, 400 + kf)
+        for lvl in range(3):
+            steps = tuple(s / (2 ** lvl) for s in (0.02, 0.02, 0.05))
+            rs = sy.render_stack(B, counts, shift_px=max(1, 4 >> lvl))
+            levels.append((kf, lvl, F, rs, capi.warp_homographies(K, counts, steps)))
+    with nmi.NmiContext(w, h, render_bottom_up=False) as ctx:
+        expected = []
+        for kf, lvl, F, rs, Ms in levels:
+            ws = ctx.warp_stack(dev(F), Ms)
+            expected.append(ctx.search_grid(dev(rs), ws))
+        with nmi.NmiStream(ctx, S, 8, depth=2) as st:
+            got, pending = [], []
+            for kf, lvl, F, rs, Ms in levels:
+                hr = torch.from_numpy(rs).pin_memory()
+                hf = torch.from_numpy(F).pin_memory()
+                # a new frame + warp stack at every level here (steps change); level 0 of each keyframe is the frame switch
+                pending.append(st.submit(hr, hf, Ms))
+                if len(pending) == 2:
+                    got.append(st.wait(pending.pop(0)))
+            while pending:
+                got.append(st.wait(pending.pop(0)))
+            # frame re-use: same frame/warps, another render stack
+            t1 = st.submit(torch.from_numpy(levels[-1][3]).pin_memory())
+            assert st.wait(t1) == expected[-1]
+            # depth exceeded without collecting -> refused, not corrupted
+            a = st.submit(torch.from_numpy(levels[0][3]).pin_memory())
+            b = st.submit(torch.from_numpy(levels[0][3]).pin_memory())
+            with pytest.raises(nmi.NmiError):
+                st.submit(torch.from_numpy(levels[0][3]).pin_memory())
+            st.wait(a), st.wait(b)
+    assert got == expected
