@@ -1,0 +1,26 @@
+"""The C++ host program on the drop-in boundary (examples/relocalize_demo.cpp): reference-style classes + C ABI + shim,
+no Python in the loop.  CPU tier: it builds and links.  GPU tier: it recovers a planted pose offset."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+EXE = os.path.join(ROOT, "examples", "relocalize_demo")
+
+
+def test_demo_builds():
+    from orbslam2_nmi_amd import build as nmi_build
+    nmi_build.build()
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    assert os.access(EXE, os.X_OK)
+
+
+@pytest.mark.gpu
+def test_demo_recovers_planted_offset():
+    assert os.access(EXE, os.X_OK), "examples/relocalize_demo must be built (python __graft_entry__.py)"
+    r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "DEMO OK" in r.stdout and "NmiKernel:" in r.stdout
