@@ -101,6 +101,26 @@ typedef struct nmi_strategy_output {
 int nmi_relocalize_with_strategy(const nmi_strategy_input *in, const nmi_properties *props, nmi_eval_grid_fn eval_grid,
                                  void *user, nmi_strategy_output *out);
 
+/*
+ * Run-time configuration surface: the Camera.* / NMI.* keys of the reference's YAML settings file, read without OpenCV
+ * (cv::FileStorage consumers: Thirdparty/Localization/localization.cpp:131-253, src/Tracking.cc:150-159;
+ * Examples/Monocular/ETH_small.yaml:8-24,62-96).  Returns 0, or <0: -2 syntax, -3 Camera.* missing, -4 NMI grid key
+ * missing, -5 file not readable.
+ */
+typedef struct nmi_config {
+    int32_t width, height;            /* Camera.Width / Camera.Height  -> nmi_params.width / height            */
+    double fx, fy, cx, cy;            /* Camera.fx..cy                 -> K of nmi_warp_homographies           */
+    nmi_search_kernel initial;        /* NMI.SynthNum[XYZ], NMI.WarpNum[XYZ], NMI.SynthStep[XYZ], NMI.WarpStep[XYZ] */
+    float nmi_threshold;              /* NMI.Treshold (sic)            -> nmi_strategy_input.nmi_threshold     */
+    int32_t init_offset;              /* NMI.Offset: frame id of the second initialisation pose               */
+    int32_t has_init1, has_init2;
+    float init1[16], init2[16];       /* NMI.Init1 / NMI.Init2, 4x4 row-major (Tracking.cc:152-159)            */
+    float render_point_size, render_near, render_far; /* NMI.Render.PointSize / NearPlane / FarPlane          */
+    char render_object[512], render_texture[512], render_cloud[512], render_offset[512]; /* NMI.Render.* paths */
+} nmi_config;
+int nmi_config_parse(const char *text, size_t len, nmi_config *out);
+int nmi_config_load(const char *yaml_path, nmi_config *out);
+
 #ifdef __cplusplus
 }
 #endif

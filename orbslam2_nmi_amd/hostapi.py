@@ -14,6 +14,7 @@ EXPORTED_SYMBOLS = (
     "nmi_properties_default", "nmi_sk_init", "nmi_sk_reset", "nmi_sk_is_middle", "nmi_sk_resize", "nmi_sk_candidates",
     "nmi_sk_format", "nmi_sk_linear_index", "nmi_sk_set_best_from_index", "nmi_find_max_elements",
     "nmi_calculate_translation", "nmi_calculate_relocalization", "nmi_mat4_inverse", "nmi_relocalize_with_strategy",
+    "nmi_config_parse", "nmi_config_load",
 )
 
 
@@ -52,6 +53,18 @@ class StrategyOutput(C.Structure):
                 ("kernel", SearchKernel), ("last_kernel", SearchKernel), ("per_iteration", SearchKernel * MAX_ITER)]
 
 
+class Config(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double),
+                ("cy", C.c_double), ("initial", SearchKernel), ("nmi_threshold", C.c_float), ("init_offset", C.c_int32),
+                ("has_init1", C.c_int32), ("has_init2", C.c_int32), ("init1", C.c_float * 16), ("init2", C.c_float * 16),
+                ("render_point_size", C.c_float), ("render_near", C.c_float), ("render_far", C.c_float),
+                ("render_object", C.c_char * 512), ("render_texture", C.c_char * 512), ("render_cloud", C.c_char * 512),
+                ("render_offset", C.c_char * 512)]
+
+    def K(self):
+        return np.array([[self.fx, 0, self.cx], [0, self.fy, self.cy], [0, 0, 1.0]])
+
+
 EVAL_GRID_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(SearchKernel), C.POINTER(C.c_float), C.POINTER(C.c_int64),
                            C.POINTER(C.c_float))
 
@@ -84,6 +97,8 @@ def _lib():
         lib.nmi_mat4_inverse.argtypes = [f32p, f32p]
         lib.nmi_relocalize_with_strategy.argtypes = [C.POINTER(StrategyInput), C.POINTER(Properties), EVAL_GRID_FN,
                                                      C.c_void_p, C.POINTER(StrategyOutput)]
+        lib.nmi_config_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Config)]
+        lib.nmi_config_load.argtypes = [C.c_char_p, C.POINTER(Config)]
         _configured = True
     return lib
 
@@ -156,6 +171,24 @@ def mat4_inverse(m):
     out = np.zeros(16, np.float32)
     assert _lib().nmi_mat4_inverse(ap, out.ctypes.data_as(C.POINTER(C.c_float))) == 0
     return out.reshape(4, 4)
+
+
+def config_parse(text):
+    """Camera.* / NMI.* keys of a reference settings file (cv::FileStorage YAML subset) -> Config; raises on errors."""
+    raw = text.encode() if isinstance(text, str) else bytes(text)
+    cfg = Config()
+    rc = _lib().nmi_config_parse(raw, len(raw), C.byref(cfg))
+    if rc != 0:
+        raise ValueError(f"nmi_config_parse failed: {rc}")
+    return cfg
+
+
+def config_load(path):
+    cfg = Config()
+    rc = _lib().nmi_config_load(str(path).encode(), C.byref(cfg))
+    if rc != 0:
+        raise ValueError(f"nmi_config_load({path}) failed: {rc}")
+    return cfg
 
 
 def relocalize_with_strategy(Tcw, initial, eval_grid, distance=(0, 0, 0), rotation=(0, 0, 0), not_initialized=False,
