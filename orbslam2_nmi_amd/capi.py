@@ -186,7 +186,12 @@ class NmiContext:
         self.close()
 
     def set_stream(self, stream_handle):
-        """Run on this hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); None = own stream."""
+        """Run on this hipStream_t (e.g. torch.cuda.Stream().cuda_stream); None = the context's own stream.
+
+        The legacy default stream has handle 0, which the C ABI reads as "own stream": callers that need stream
+        ordering with torch work (collectives, tensor reads) must make a non-default torch stream current and pass it."""
+        if stream_handle == 0:
+            raise ValueError("handle 0 is the legacy default stream; use a torch.cuda.Stream() (non-default) instead")
         self._check(self._lib.nmi_set_stream(self._h, C.c_void_p(stream_handle)), "nmi_set_stream")
 
     OPT_HIST_VARIANT, OPT_PHASE_MASK, OPT_WORKGROUPS, OPT_RESULT_PATH = 1, 2, 3, 4

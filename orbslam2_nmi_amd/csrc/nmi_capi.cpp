@@ -291,8 +291,11 @@ int nmi_create(const nmi_params *params, nmi_ctx **out_ctx)
         return fail(e, "hipMalloc(table)");
     if ((e = hipMalloc((void **)&ctx->d_keys, 2 * sizeof(unsigned long long))) != hipSuccess) return fail(e, "hipMalloc(key)");
     if ((e = hipMalloc((void **)&ctx->d_done, sizeof(unsigned int))) != hipSuccess) return fail(e, "hipMalloc(done)");
-    if ((e = hipMemset(ctx->d_keys, 0, 2 * sizeof(unsigned long long))) != hipSuccess) return fail(e, "hipMemset(key)");
-    if ((e = hipMemset(ctx->d_done, 0, sizeof(unsigned int))) != hipSuccess) return fail(e, "hipMemset(done)");
+    // on the context's own (non-blocking) stream: a legacy-stream hipMemset is not ordered against it
+    if ((e = hipMemsetAsync(ctx->d_keys, 0, 2 * sizeof(unsigned long long), ctx->stream)) != hipSuccess)
+        return fail(e, "hipMemsetAsync(key)");
+    if ((e = hipMemsetAsync(ctx->d_done, 0, sizeof(unsigned int), ctx->stream)) != hipSuccess)
+        return fail(e, "hipMemsetAsync(done)");
     if ((e = hipHostMalloc((void **)&ctx->mailbox, sizeof(nmi::Mailbox), hipHostMallocCoherent | hipHostMallocMapped)) !=
         hipSuccess)
         return fail(e, "hipHostMalloc(mailbox)");

@@ -35,8 +35,9 @@ def allreduce_key(key_tensor, dist, group=None):
 def sharded_search(ctx, render_shard_stack, s_offset, s_total, warp_stack, key_tensor, dist=None, group=None):
     """One rank's step: HIP kernel on the local shard -> key on the device -> all-reduce -> (index, score) on host.
 
-    ctx must run on the current torch stream (ctx.set_stream(torch.cuda.current_stream().cuda_stream)) so that the
-    collective is ordered after the kernel."""
+    ctx must run on the current torch stream, and that stream must not be the legacy default one
+    (s = torch.cuda.Stream(); torch.cuda.set_stream(s); ctx.set_stream(s.cuda_stream)), so that the collective and
+    the read-back are ordered after the kernel."""
     ctx.search_grid_shard(render_shard_stack, s_offset, s_total, warp_stack, key_out=key_tensor, blocking=False)
     if dist is not None:
         allreduce_key(key_tensor, dist, group)
