@@ -363,7 +363,7 @@ int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value)
         ctx->hist_variant = (int)value;
         return NMI_OK;
     case NMI_OPT_PHASE_MASK:
-        if (value < 0 || value > 3) return NMI_ERR_INVALID_ARGUMENT;
+        if (value < 0 || value > 7) return NMI_ERR_INVALID_ARGUMENT;
         ctx->phase_mask = (int)value;
         return NMI_OK;
     case NMI_OPT_RESULT_PATH:

@@ -131,7 +131,7 @@ __device__ __forceinline__ void add_pixel(Lds &lds, int par, uint32_t d1, uint32
 //   2  non-returning atomics, no test: exact only when no bin can exceed 65535 (first try of the
 //      optimistic scheme HIST = 3, see nmi_grid_kernel)
 template <bool BG, bool SHIFTED, int HIST>
-__device__ __forceinline__ void add_chunk(Lds &lds, int par, const uint4 &rv, const uint4 &wv, int shift)
+__device__ __forceinline__ void add_chunk(Lds &lds, int par, const uint4 &rv, const uint4 &wv, int shift, bool try_flat)
 {
     const uint32_t r[4] = {rv.x, rv.y, rv.z, rv.w};
     const uint32_t w[4] = {wv.x, wv.y, wv.z, wv.w};
@@ -142,6 +142,45 @@ __device__ __forceinline__ void add_chunk(Lds &lds, int par, const uint4 &rv, co
             for (int j = 0; j < 4; ++j)
                 add_pixel<BG, SHIFTED>(lds, par, (r[q] >> (8 * j)) & 0xFFu, (w[q] >> (8 * j)) & 0xFFu, shift);
         return;
+    }
+    // Flat chunks: when, for every active lane of the wavefront, all 16 pixels carry the same (render, frame) pair --
+    // render background over frame border, saturated regions -- the 16 updates of a lane collapse into one weighted
+    // add, and if the whole wavefront agrees on the pair, into a single add by one lane.  Otherwise 64 lanes would
+    // queue 16 times on one LDS address (2 cycles per lane each time).
+    // Only the exact path looks for them: it runs when a candidate has a bin above 65535 hits, which is exactly the data
+    // that has such regions, and the test costs ~10 % of the histogram phase when it never fires.
+    if (HIST == 1 && try_flat) {
+        const uint32_t rb = r[0] & 0xFFu, wb = w[0] & 0xFFu;
+        const bool flat = r[0] == r[1] && r[1] == r[2] && r[2] == r[3] && w[0] == w[1] && w[1] == w[2] && w[2] == w[3] &&
+                          r[0] == rb * 0x01010101u && w[0] == wb * 0x01010101u;
+        if (__builtin_expect(__all(flat), 0)) {
+            uint32_t d1 = rb, d2 = wb;
+            const bool skip = !BG && (d1 == 0 || d2 == 0);  // NMI.cu:85
+            if (SHIFTED) {
+                d1 >>= shift;
+                d2 >>= shift;
+            }
+            const uint32_t key = (d1 << 8) | d2;
+            const uint32_t key0 = __builtin_amdgcn_readfirstlane(key);
+            const bool skip0 = __builtin_amdgcn_readfirstlane((uint32_t)skip) != 0;
+            uint32_t weight = 16;
+            bool issue = !skip;
+            if (__all(key == key0 && skip == skip0)) {  // one lane speaks for the wavefront
+                weight = 16u * (uint32_t)__popcll(__ballot(1));
+                issue = issue && (__lane_id() == (uint32_t)__ffsll((long long)__ballot(1)) - 1u);
+            }
+            if (issue) {
+                const uint32_t word = joint_word(d1, d2), high = d2 >> 7, inc = high ? weight << 16 : weight;
+                if (HIST == 2) {
+                    (void)__hip_atomic_fetch_add(&lds.joint[word], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    const uint32_t old = __hip_atomic_fetch_add(&lds.joint[word], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t field_old = high ? old >> 16 : old & 0xFFFFu;
+                    if (field_old + weight > 0xFFFFu) record_wrap(lds, par, word, high ? 0x10000u : 1u, high ? old : (old | 0xFFFFu));
+                }
+            }
+            return;
+        }
     }
     uint32_t old[16];
     uint32_t any = 0;  // max over pixels of (old | ~field): 0xFFFFFFFF iff some counter wrapped
@@ -216,6 +255,7 @@ __device__ __forceinline__ void histogram_phase(Lds &lds, int par, const GridArg
         // the current chunk's 16 atomics issue.  Loads are unconditional (index clamped to the last chunk, a valid
         // address) so the code is straight-line and the compiler can wait on exact load counts; only the atomics
         // are predicated on the chunk being in range.
+        const bool try_flat = !(a.phase_mask & 4);  // ablation switch for the flat-chunk shortcut
         const int last = nchunks - 1;
         const int iters = (nchunks + kBlock - 1) / kBlock;  // workgroup-uniform
         int ch = tid;
@@ -225,11 +265,11 @@ __device__ __forceinline__ void histogram_phase(Lds &lds, int par, const GridArg
             const int c1 = min(ch + kBlock, last);
             wb = wp[c1];
             rb = rp[render_chunk(c1)];
-            if (ch < nchunks) add_chunk<BG, SHIFTED, HIST>(lds, par, ra, wa, a.shift);
+            if (ch < nchunks) add_chunk<BG, SHIFTED, HIST>(lds, par, ra, wa, a.shift, try_flat);
             const int c2 = min(ch + 2 * kBlock, last);
             wa = wp[c2];
             ra = rp[render_chunk(c2)];
-            if (ch + kBlock < nchunks) add_chunk<BG, SHIFTED, HIST>(lds, par, rb, wb, a.shift);
+            if (ch + kBlock < nchunks) add_chunk<BG, SHIFTED, HIST>(lds, par, rb, wb, a.shift, try_flat);
             ch += 2 * kBlock;
         }
     } else {
@@ -462,6 +502,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
     if (tid < kBins) lds.hist_warped[tid] = 0;
     if (tid < 2) lds.ovf_n[tid] = lds.total[tid] = 0;
     bool table_pending = true;
+    bool degenerate = false;  // workgroup-uniform
     __syncthreads();
 
     const int total = a.S_local * a.Wn;
@@ -473,7 +514,15 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
         const uint8_t *render = a.render_stack + (size_t)s * a.npix;
         const uint8_t *warped = a.warp_stack + (size_t)w * a.npix;
 
-        if (a.phase_mask & 1) histogram_phase<BG, SHIFTED, kFirst>(lds, par, a, render, warped);
+        // A workgroup that has met a candidate with wrapped counters expects more of them (same frame, same renders)
+        // and goes straight to the exact path, which also folds flat regions.
+        const bool exact_first = kOptimistic && degenerate;
+        if (a.phase_mask & 1) {
+            if (exact_first)
+                histogram_phase<BG, SHIFTED, 1>(lds, par, a, render, warped);
+            else
+                histogram_phase<BG, SHIFTED, kFirst>(lds, par, a, render, warped);
+        }
         if (table_pending) {
 #pragma unroll
             for (int k = 0; k < kLdsTable / kBlock; ++k) lds.table[tid + k * kBlock] = tab[k];
@@ -482,8 +531,9 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
         __syncthreads();  // B1
         if (a.phase_mask & 2) decode_phase(lds, par, a, wave, lane);
         __syncthreads();  // B2
-        if (kOptimistic && a.phase_mask == 3 && lds.total[par] != (uint32_t)a.npix) {
+        if (kOptimistic && !exact_first && (a.phase_mask & 3) == 3 && lds.total[par] != (uint32_t)a.npix) {
             // Some counter wrapped (workgroup-uniform, rare): redo this candidate exactly.
+            degenerate = true;
             __syncthreads();
             if (tid < kBins) lds.hist_warped[tid] = 0;
             if (tid == 0) lds.total[par] = 0;

@@ -44,7 +44,7 @@ def main():
         datasets["constant"] = (np.full((S, H, W), 255, np.uint8), np.zeros((Wn, H, W), np.uint8))
     dev = {k: (torch.from_numpy(r).cuda(), torch.from_numpy(w).cuda()) for k, (r, w) in datasets.items()}
 
-    variants = [("hist1 full", 1, 3), ("hist2 full", 2, 3), ("hist3 full", 3, 3),
+    variants = [("hist1 full", 1, 3), ("hist2 full", 2, 3), ("hist3 full", 3, 3), ("hist3 full noflat", 3, 7),
                 ("hist1 hist-only", 1, 1), ("hist2 hist-only", 2, 1),
                 ("decode-only", 3, 2), ("empty loop", 3, 0)]
     ctx = nmi.NmiContext(W, H)
