@@ -190,7 +190,9 @@ int nmi_last_kernel_ms(nmi_ctx *ctx, float *h_ms);
  * Tuning / ablation knobs (defaults are the shipped configuration; results stay exact for every value
  * except NMI_OPT_HIST_VARIANT = 2, which skips the counter-wrap bookkeeping, and a partial phase mask).
  */
-#define NMI_OPT_HIST_VARIANT 1 /* 0 per-pixel wrap test, 1 batched wrap test, 2 unchecked, 3 optimistic + verify + exact redo (default) */
+#define NMI_OPT_HIST_VARIANT 1 /* 0 per-pixel wrap test, 1 batched wrap test, 2 unchecked, 3 optimistic + verify + exact redo
+                                  (default), 4 = 3 with histogram and decode overlapped by wavefront role (experimental:
+                                  exact, but measured slower than 3 -- DESIGN.md section 4) */
 #define NMI_OPT_PHASE_MASK 2   /* bit 0 histogram phase, bit 1 decode + score, bit 2 disable the flat-chunk shortcut; default 3 */
 #define NMI_OPT_WORKGROUPS 3   /* workgroups per launch; 0 = one per compute unit (default) */
 #define NMI_OPT_RESULT_PATH 4  /* how the 8-byte winner reaches the host: 1 the kernel posts it to pinned host memory

@@ -37,6 +37,8 @@ struct nmi_ctx {
     int result_path = 1;                   // 1 mailbox spin (default), 0 hipMemcpyAsync + stream sync
     bool posted = false;                   // the most recent launch posts to the mailbox
     float *d_pair_rating = nullptr;
+    uint32_t *d_scratch = nullptr;        // drained-counter slabs of the pipelined kernel
+    int scratch_workgroups = 0;
     // inverse homographies for the warp producer: a small ring of (pinned staging, device copy, "copy consumed" event)
     // so that back-to-back submissions never wait for the stream
     static constexpr int kWarpRing = 4;
@@ -119,6 +121,7 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     a.mode = p.mode;
     a.flip = p.render_bottom_up ? 1 : 0;
     a.table = ctx->table;
+    a.scratch = ctx->d_scratch;
     a.ratings = d_ratings;
     a.key = ctx->d_keys + ctx->slot;
     a.reset_key = ctx->d_keys + (ctx->slot ^ 1);
@@ -150,6 +153,16 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     ctx->slot ^= 1;
     const int cap = ctx->workgroups > 0 ? ctx->workgroups : ctx->compute_units;
     const int workgroups = (int)(total < cap ? total : cap);
+    if (ctx->hist_variant == 4 && workgroups > ctx->scratch_workgroups) {
+        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_scratch) NMI_HIP_TRY(ctx, hipFree(ctx->d_scratch));
+        ctx->d_scratch = nullptr;
+        ctx->scratch_workgroups = 0;
+        const int alloc = workgroups > ctx->compute_units ? workgroups : ctx->compute_units;
+        NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_scratch, nmi::grid_kernel_scratch_bytes(alloc)));
+        ctx->scratch_workgroups = alloc;
+        a.scratch = ctx->d_scratch;
+    }
     if (ctx->profiling) NMI_HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     NMI_HIP_TRY(ctx, nmi::launch_grid(a, workgroups, p.use_bg != 0, ctx->stream));
     if (ctx->profiling) {
@@ -326,6 +339,7 @@ int nmi_destroy(nmi_ctx *ctx)
     if (ctx->d_done) (void)hipFree(ctx->d_done);
     if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
     if (ctx->d_pair_rating) (void)hipFree(ctx->d_pair_rating);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     for (int i = 0; i < nmi_ctx::kWarpRing; ++i) {
         if (ctx->d_warp_coeffs[i]) (void)hipFree(ctx->d_warp_coeffs[i]);
         if (ctx->h_warp_coeffs[i]) (void)hipHostFree(ctx->h_warp_coeffs[i]);
@@ -359,11 +373,11 @@ int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value)
     if (!ctx) return NMI_ERR_INVALID_ARGUMENT;
     switch (option) {
     case NMI_OPT_HIST_VARIANT:
-        if (value < 0 || value > 3) return NMI_ERR_INVALID_ARGUMENT;
+        if (value < 0 || value > 4) return NMI_ERR_INVALID_ARGUMENT;
         ctx->hist_variant = (int)value;
         return NMI_OK;
     case NMI_OPT_PHASE_MASK:
-        if (value < 0 || value > 7) return NMI_ERR_INVALID_ARGUMENT;
+        if (value < 0 || value > 15) return NMI_ERR_INVALID_ARGUMENT;
         ctx->phase_mask = (int)value;
         return NMI_OK;
     case NMI_OPT_RESULT_PATH:

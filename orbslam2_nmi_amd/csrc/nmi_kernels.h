@@ -29,6 +29,7 @@ struct GridArgs {
     int mode;                     // NMI_MODE_*_
     int flip;                     // render stored bottom-up (NMI.cu:82)
     const float *table;           // [npix + 1] per-count entropy terms
+    uint32_t *scratch;            // pipelined kernel: [workgroups][2][32768] drained packed counters
     float *ratings;               // [Wn][S_local] or nullptr
     unsigned long long *key;      // packed arg-max slot of this launch (zero on entry)
     unsigned long long *reset_key;  // the slot of the next launch: cleared by this one (ping-pong), or nullptr
@@ -38,13 +39,14 @@ struct GridArgs {
     unsigned int seq;               // sequence number of this posting launch (its parity is posted with the winner)
     uint32_t *dbg_joint, *dbg_h1, *dbg_h2;
     float *dbg_sums;
-    int hist_variant;             // 0 per-pixel wrap test, 1 batched wrap test, 2 unchecked (ablation), 3 optimistic + verify (default)
+    int hist_variant;             // 0 per-pixel wrap test, 1 batched, 2 unchecked (ablation), 3 optimistic + verify (default), 4 pipelined (experimental)
     int phase_mask;               // bit 0 histogram phase, bit 1 decode + score (ablation; product uses 3)
 };
 
 hipError_t launch_table(float *table, int npix, hipStream_t stream);
 hipError_t launch_grid(const GridArgs &a, int workgroups, bool use_bg, hipStream_t stream);
 int grid_kernel_lds_bytes();
+size_t grid_kernel_scratch_bytes(int workgroups);
 hipError_t launch_warp(const uint8_t *frame, const float *coeffs /*[Wn][9] inverse maps*/, uint8_t *out, int width,
                        int height, int Wn, hipStream_t stream);
 

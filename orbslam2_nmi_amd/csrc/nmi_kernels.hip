@@ -45,6 +45,9 @@ struct Lds {
     uint32_t ovf_n[2];
     uint32_t total[2];            // sum of all decoded counters of the candidate (wrap detector), by parity
     float table[kLdsTable];       // table[c] for c < kLdsTable (16 KiB); larger counts read the global table
+    uint32_t fallback;            // pipelined kernel: a candidate wrapped, finish sequentially on the exact path
+    uint32_t redo_n;
+    uint32_t redo[4];             // ordinals (within this workgroup) of candidates to score again exactly
 };
 
 // ---- cross-lane helpers (DPP within a row of 16 lanes: lane i receives lane i + N) -------------------
@@ -234,11 +237,11 @@ __device__ __forceinline__ void add_chunk(Lds &lds, int par, const uint4 &rv, co
 }
 
 // Histogram phase for one candidate: histogram256Kernel's pixel loop, NMI.cu:79-87.
-template <bool BG, bool SHIFTED, int HIST>
+// NT lanes (tid = 0..NT-1) share the pixels of the candidate.
+template <bool BG, bool SHIFTED, int HIST, int NT>
 __device__ __forceinline__ void histogram_phase(Lds &lds, int par, const GridArgs &a, const uint8_t *__restrict__ render,
-                                                const uint8_t *__restrict__ warped)
+                                                const uint8_t *__restrict__ warped, int tid)
 {
-    const int tid = threadIdx.x;
     if (a.vec_ok) {
         // 16 pixels per lane per step: one 16-byte load from each image (1 KiB per wavefront instruction),
         // the next step's loads issued before this step's atomics.
@@ -257,24 +260,24 @@ __device__ __forceinline__ void histogram_phase(Lds &lds, int par, const GridArg
         // are predicated on the chunk being in range.
         const bool try_flat = !(a.phase_mask & 4);  // ablation switch for the flat-chunk shortcut
         const int last = nchunks - 1;
-        const int iters = (nchunks + kBlock - 1) / kBlock;  // workgroup-uniform
+        const int iters = (nchunks + NT - 1) / NT;  // workgroup-uniform
         int ch = tid;
         int c0 = min(ch, last);
         uint4 wa = wp[c0], ra = rp[render_chunk(c0)], wb, rb;
         for (int it = 0; it < iters; it += 2) {
-            const int c1 = min(ch + kBlock, last);
+            const int c1 = min(ch + NT, last);
             wb = wp[c1];
             rb = rp[render_chunk(c1)];
             if (ch < nchunks) add_chunk<BG, SHIFTED, HIST>(lds, par, ra, wa, a.shift, try_flat);
-            const int c2 = min(ch + 2 * kBlock, last);
+            const int c2 = min(ch + 2 * NT, last);
             wa = wp[c2];
             ra = rp[render_chunk(c2)];
-            if (ch + kBlock < nchunks) add_chunk<BG, SHIFTED, HIST>(lds, par, rb, wb, a.shift, try_flat);
-            ch += 2 * kBlock;
+            if (ch + NT < nchunks) add_chunk<BG, SHIFTED, HIST>(lds, par, rb, wb, a.shift, try_flat);
+            ch += 2 * NT;
         }
     } else {
         // Any width / alignment: byte loads, position arithmetic as written in NMI.cu:79-83.
-        for (int pos = tid; pos < a.npix; pos += kBlock) {
+        for (int pos = tid; pos < a.npix; pos += NT) {
             const int y = pos / a.width;
             const int x = pos - y * a.width;
             const int ry = a.flip ? (a.height - 1 - y) : y;
@@ -519,9 +522,11 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
         const bool exact_first = kOptimistic && degenerate;
         if (a.phase_mask & 1) {
             if (exact_first)
-                histogram_phase<BG, SHIFTED, 1>(lds, par, a, render, warped);
-            else
-                histogram_phase<BG, SHIFTED, kFirst>(lds, par, a, render, warped);
+                histogram_phase<BG, SHIFTED, 1, kBlock>(lds, par, a, render, warped, tid);
+            else if (a.phase_mask & 8) {  // ablation: only half of the wavefronts take part in the histogram phase
+                if (wave < kWaves / 2) histogram_phase<BG, SHIFTED, kFirst, kBlock / 2>(lds, par, a, render, warped, tid);
+            } else
+                histogram_phase<BG, SHIFTED, kFirst, kBlock>(lds, par, a, render, warped, tid);
         }
         if (table_pending) {
 #pragma unroll
@@ -538,7 +543,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
             if (tid < kBins) lds.hist_warped[tid] = 0;
             if (tid == 0) lds.total[par] = 0;
             __syncthreads();
-            histogram_phase<BG, SHIFTED, 1>(lds, par, a, render, warped);
+            histogram_phase<BG, SHIFTED, 1, kBlock>(lds, par, a, render, warped, tid);
             __syncthreads();
             decode_phase(lds, par, a, wave, lane);
             __syncthreads();
@@ -561,6 +566,250 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
     // 8-byte store (key in bits 0..62, launch parity in bit 63 -- scores are non-negative floats, bit 63 is free).
     if (tid == 0) {
         const unsigned int one = prev_key == ~0ull ? 2u : 1u;  // always 1 (a key never has all bits set)
+        const unsigned int arrived = __hip_atomic_fetch_add(a.done, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == gridDim.x - 1) {
+            const unsigned long long final_key = __hip_atomic_load(a.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.out_key) *a.out_key = final_key;
+            if (a.mailbox)
+                __hip_atomic_store(&a.mailbox->word, final_key | ((unsigned long long)(a.seq & 1u) << 63), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Pipelined ("wavefront-specialised") form of the same computation (NMI_OPT_HIST_VARIANT = 4, experimental).
+// Exact, covered by the parity tests, but measured SLOWER than the sequential kernel on MI355X (114 vs 95 us per 729
+// candidates): the decode wavefronts take issue slots from the histogram wavefronts, 8 histogram wavefronts add
+// pixels 22 % slower than 16, and the drain is a third serial step.  Kept as an ablation; see DESIGN.md section 4.
+//
+// The histogram phase is bound by the LDS atomic unit, the decode arithmetic by VALU issue and latency; run one
+// after the other (kernel above) a CU leaves each unit idle in turn.  Here the 16 wavefronts split into
+//   H = wavefronts 0..7   histogram phase of candidate k (non-returning atomics into the packed LDS joint)
+//   D = wavefronts 8..15  decode arithmetic of candidate k-1 (terms, trees, marginals) from its drained counters
+// with two workgroup barriers per candidate: X (histogram k and arithmetic k-1 done) and Y (all wavefronts have
+// drained candidate k's packed counters from LDS to the workgroup's scratch slab in L2 and cleared the LDS words;
+// meanwhile wavefront 0 forms the score of k-1).  D then reads candidate k back from the slab while H is already
+// adding candidate k+1.  Only the drain (an LDS read + clear sweep with coalesced stores) stays serial with H.
+// Counter wraps are detected by the pixel-count test as before; the first wrapped candidate switches the
+// workgroup to the sequential exact path (below) for that candidate and all that follow.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kHalf = kBlock / 2;               // lanes per role
+constexpr int kDWaves = kWaves / 2;             // 8 decode wavefronts
+constexpr int kDRows = kBins / kDWaves;         // 32 joint rows per decode wavefront
+constexpr int kDPasses = kDRows / 4;            // 8 passes of 4 rows (one per 16-lane DPP row)
+
+// Drain, all 16 wavefronts: packed counters LDS -> this workgroup's scratch slab in global memory (it stays in L2),
+// clearing the LDS words.  The slab is written in the order the decode wavefronts read it -- [dwave][pass][k][lane],
+// 256 contiguous bytes per wavefront instruction -- with the word ownership of decode_phase (lane i of a 16-lane row
+// owns words i + 16*k of its joint row).
+__device__ __forceinline__ void drain_to_scratch(Lds &lds, uint32_t *__restrict__ slab, int wave, int lane)
+{
+    const int i = lane & 15, r = lane >> 4, o = r & 1;
+    const int dwave = wave >> 1, pass0 = (wave & 1) * (kDPasses / 2);
+#pragma unroll
+    for (int pp = 0; pp < kDPasses / 2; ++pp) {
+        const int pass = pass0 + pp;
+        const int d1 = dwave * kDRows + pass * 4 + r;
+        const uint32_t a0 = d1 * 128 + i + 16 * o;
+        uint32_t wd[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t idx = k < 7 ? a0 + 16 * k : a0 + 112 - 128 * o;
+            wd[k] = lds.joint[idx];
+            lds.joint[idx] = 0;
+        }
+        uint32_t *dst = slab + ((dwave * kDPasses + pass) * 8) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[k * 64] = wd[k];
+    }
+}
+
+// D: per-bin terms, row trees, marginals for the 32 rows of this decode wavefront, read back from the slab
+// (agent-scope loads: the slab was written by other wavefronts of this CU through L2, this CU's L1 may hold the
+// lines of an earlier candidate).  The next pass's words are in flight while the current pass is reduced.
+__device__ __forceinline__ void load_pass(const uint32_t *__restrict__ src, uint32_t (&wd)[8])
+{
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wd[k] = __hip_atomic_load(src + k * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void decode_pass(Lds &lds, const GridArgs &a, int d1, int i, const uint32_t (&wd)[8],
+                                            uint32_t (&col_lo)[8], uint32_t (&col_hi)[8], uint32_t &wave_total)
+{
+    uint32_t lo[8], hi[8], rsum = 0, cmax = 0;
+    float tl[8], th[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        lo[k] = wd[k] & 0xFFFFu;
+        hi[k] = wd[k] >> 16;
+        col_lo[k] += lo[k];
+        col_hi[k] += hi[k];
+        rsum += lo[k] + hi[k];
+        cmax = max(cmax, max(lo[k], hi[k]));
+        tl[k] = lds.table[lo[k] & (kLdsTable - 1)];
+        th[k] = lds.table[hi[k] & (kLdsTable - 1)];
+    }
+    if (__builtin_expect(cmax >= (uint32_t)kLdsTable, 0)) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (lo[k] >= (uint32_t)kLdsTable) tl[k] = a.table[lo[k]];
+            if (hi[k] >= (uint32_t)kLdsTable) th[k] = a.table[hi[k]];
+        }
+    }
+    rsum = row_sum_16(rsum);
+    wave_total += rsum;
+    const float x = row_tree_16(lane_tree_16(tl, th));
+    if (i == 0) {
+        lds.hist_render[d1] = rsum;
+        lds.joint_row_sums[d1] = x;
+    }
+}
+
+__device__ __forceinline__ void decode_from_scratch(Lds &lds, const GridArgs &a, const uint32_t *__restrict__ slab, int dwave,
+                                                    int lane)
+{
+    const int i = lane & 15, r = lane >> 4, o = r & 1;
+    uint32_t col_lo[8], col_hi[8], wave_total = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) col_lo[k] = col_hi[k] = 0;
+    const uint32_t *src = slab + (dwave * kDPasses * 8) * 64 + lane;
+    uint32_t wa[8], wb[8];
+    load_pass(src, wa);
+#pragma unroll 1
+    for (int pass = 0; pass < kDPasses; pass += 2) {
+        load_pass(src + (pass + 1) * 8 * 64, wb);
+        decode_pass(lds, a, dwave * kDRows + pass * 4 + r, i, wa, col_lo, col_hi, wave_total);
+        if (pass + 2 < kDPasses) load_pass(src + (pass + 2) * 8 * 64, wa);
+        decode_pass(lds, a, dwave * kDRows + (pass + 1) * 4 + r, i, wb, col_lo, col_hi, wave_total);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int q = (i + 16 * (k + o)) & 127;
+        atomicAdd(&lds.hist_warped[q], col_lo[k]);
+        atomicAdd(&lds.hist_warped[q + 128], col_hi[k]);
+    }
+    if (i == 0) atomicAdd(&lds.total[0], wave_total);
+}
+
+// One candidate start to finish on the exact path, all 16 wavefronts (the sequential kernel's loop body).
+template <bool SHIFTED>
+__device__ __noinline__ void exact_candidate(Lds &lds, const GridArgs &a, int tid, int p, unsigned long long &prev_key)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const int w = p / a.S_local, s = p - w * a.S_local;
+    histogram_phase<true, SHIFTED, 1, kBlock>(lds, 0, a, a.render_stack + (size_t)s * a.npix, a.warp_stack + (size_t)w * a.npix, tid);
+    __syncthreads();
+    decode_phase(lds, 0, a, wave, lane);
+    __syncthreads();
+    if (wave == 0) {
+        final_phase(lds, a, lane, p, w, s, prev_key);
+        for (int t = lane; t < kBins; t += 64) lds.hist_warped[t] = 0;
+        if (lane == 0) lds.ovf_n[0] = lds.total[0] = 0;
+    }
+    __syncthreads();
+}
+
+}  // namespace
+
+template <bool SHIFTED>
+__global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel_ws(GridArgs a)
+{
+    __shared__ Lds lds;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const bool is_hist = wave < kDWaves;  // wavefront-uniform role
+    const int dwave = wave - kDWaves;
+
+    if (blockIdx.x == 0 && tid == 0 && a.reset_key) *a.reset_key = 0ull;
+    {
+        uint4 *j4 = reinterpret_cast<uint4 *>(lds.joint);
+        const uint4 z = {0, 0, 0, 0};
+        for (int i = tid; i < kWords / 4; i += kBlock) j4[i] = z;
+    }
+    for (int c = tid; c < kLdsTable; c += kBlock) lds.table[c] = a.table[c <= a.npix ? c : 0];
+    if (tid < kBins) lds.hist_warped[tid] = 0;
+    if (tid < 2) lds.ovf_n[tid] = lds.total[tid] = 0;
+    if (tid == 0) lds.fallback = lds.redo_n = 0;
+    __syncthreads();
+
+    const int total = a.S_local * a.Wn;
+    const int n = (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;  // candidates of this workgroup (>= 1)
+    unsigned long long prev_key = 0;
+    // two slabs per workgroup, alternating by candidate: D reads slab (k-1)&1 while the drain of candidate k fills slab k&1
+    uint32_t *const slab0 = a.scratch + (size_t)blockIdx.x * 2 * kWords;
+
+    int k = 0;        // stage: H works on candidate k, D on candidate k-1
+    bool bail = false;
+    for (; k <= n && !bail; ++k) {
+        const int p = (int)blockIdx.x + k * (int)gridDim.x;
+        if (is_hist) {
+            if (k < n && (a.phase_mask & 1)) {
+                const int w = p / a.S_local, s = p - w * a.S_local;
+                histogram_phase<true, SHIFTED, 2, kHalf>(lds, 0, a, a.render_stack + (size_t)s * a.npix,
+                                                         a.warp_stack + (size_t)w * a.npix, tid);
+            }
+        } else if (k > 0 && (a.phase_mask & 2)) {
+            decode_from_scratch(lds, a, slab0 + ((k - 1) & 1) * kWords, dwave, lane);
+        }
+        __syncthreads();  // X
+        if (k < n && !(a.phase_mask & 4)) drain_to_scratch(lds, slab0 + (k & 1) * kWords, wave, lane);
+        if (is_hist) {
+            if (wave == 0 && k > 0) {
+                const int pp = p - (int)gridDim.x, w = pp / a.S_local, s = pp - w * a.S_local;
+                if ((a.phase_mask & 7) == 3 && lds.total[0] != (uint32_t)a.npix) {
+                    // a 16-bit counter wrapped in candidate k-1: hand it (and everything after it) to the exact path
+                    if (lane == 0) {
+                        lds.fallback = 1;
+                        lds.redo[lds.redo_n++] = (uint32_t)(k - 1);
+                    }
+                } else {
+                    final_phase(lds, a, lane, pp, w, s, prev_key);
+                }
+                for (int t = lane; t < kBins; t += 64) lds.hist_warped[t] = 0;
+                if (lane == 0) lds.total[0] = 0;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);  // the slab stores of this wavefront have reached L2 before anyone is released
+        __syncthreads();  // Y
+        bail = lds.fallback != 0;
+    }
+
+    if (bail) {
+        // Stage k-1 detected the wrap; candidate k-1 (if any) has already been drained into the D registers.
+        const int kd = k - 1;  // ordinal of the drained candidate
+        if (kd < n) {
+            if (!is_hist) decode_from_scratch(lds, a, slab0 + (kd & 1) * kWords, dwave, lane);
+            __syncthreads();
+            if (wave == 0) {
+                const int pp = (int)blockIdx.x + kd * (int)gridDim.x, w = pp / a.S_local, s = pp - w * a.S_local;
+                if (lds.total[0] != (uint32_t)a.npix) {
+                    if (lane == 0) lds.redo[lds.redo_n++] = (uint32_t)kd;
+                } else {
+                    final_phase(lds, a, lane, pp, w, s, prev_key);
+                }
+                for (int t = lane; t < kBins; t += 64) lds.hist_warped[t] = 0;
+                if (lane == 0) lds.total[0] = 0;
+            }
+            __syncthreads();
+        }
+        // The exact path is a real call (keeps its registers out of the pipelined loops); it gets its own copy of the
+        // arguments so that the kernel's copy never has its address taken and stays in scalar registers.
+        GridArgs a_exact = a;
+        const int nredo = (int)lds.redo_n;
+        for (int e = 0; e < nredo; ++e)
+            exact_candidate<SHIFTED>(lds, a_exact, tid, (int)blockIdx.x + (int)lds.redo[e] * (int)gridDim.x, prev_key);
+        for (int kk = kd + 1; kk < n; ++kk)
+            exact_candidate<SHIFTED>(lds, a_exact, tid, (int)blockIdx.x + kk * (int)gridDim.x, prev_key);
+    }
+
+    // completion: identical to the sequential kernel
+    if (tid == 0) {
+        const unsigned int one = prev_key == ~0ull ? 2u : 1u;
         const unsigned int arrived = __hip_atomic_fetch_add(a.done, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (arrived == gridDim.x - 1) {
             const unsigned long long final_key = __hip_atomic_load(a.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -621,18 +870,32 @@ hipError_t launch_grid(const GridArgs &a, int workgroups, bool use_bg, hipStream
     case 0: launch_hist<0>(a, grid, block, use_bg, stream); break;
     case 1: launch_hist<1>(a, grid, block, use_bg, stream); break;
     case 2: launch_hist<2>(a, grid, block, use_bg, stream); break;
-    default:
+    case 3:
         // The wrap detector of HIST = 3 needs the expected pixel count, which is W*H only with BG on.
         if (use_bg)
             launch_hist<3>(a, grid, block, use_bg, stream);
         else
             launch_hist<1>(a, grid, block, use_bg, stream);
         break;
+    default:
+        // 4 = pipelined kernel (experimental).  It has no debug exports and needs BG on.
+        if (use_bg && !a.dbg_joint && !a.dbg_h1 && !a.dbg_h2 && !a.dbg_sums) {
+            if (a.shift != 0)
+                hipLaunchKernelGGL((nmi_grid_kernel_ws<true>), grid, block, 0, stream, a);
+            else
+                hipLaunchKernelGGL((nmi_grid_kernel_ws<false>), grid, block, 0, stream, a);
+        } else if (use_bg) {
+            launch_hist<3>(a, grid, block, use_bg, stream);
+        } else {
+            launch_hist<1>(a, grid, block, use_bg, stream);
+        }
+        break;
     }
     return hipGetLastError();
 }
 
 int grid_kernel_lds_bytes() { return (int)sizeof(Lds); }
+size_t grid_kernel_scratch_bytes(int workgroups) { return (size_t)workgroups * 2 * kWords * sizeof(uint32_t); }
 
 // ---------------------------------------------------------------------------------------------------------
 // Warp-stack producer: Image::calculateWarping, Thirdparty/Localization/image.cpp:115-128 --

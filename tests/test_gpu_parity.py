@@ -374,3 +374,22 @@ def test_streaming_pipeline_matches_sequential(nmi):
                 st.submit(torch.from_numpy(levels[0][3]).pin_memory())
             st.wait(a), st.wait(b)
     assert got == expected
+
+
+@pytest.mark.parametrize("variant", [0, 1, 3, 4])
+def test_kernel_variants_agree(nmi, variant):
+    """Every exact kernel variant (NMI_OPT_HIST_VARIANT) gives the oracle's table, also on data that wraps counters."""
+    from oracle import binding as oc
+    from orbslam2_nmi_amd import synthetic as sy
+    wl = sy.workload(320, 240, 9, 30, seed=3)          # 270 candidates: several per workgroup when capped below
+    rs, ws = wl["render_stack"].copy(), wl["warp_stack"].copy()
+    rs[4] = 255                                         # a constant render (76,800 px)...
+    ws[7] = 0                                           # ...over a constant frame: one bin gets 76,800 > 65,535 hits
+    ro, io, bo = oc.search_grid(rs, ws, threads=16)
+    with nmi.NmiContext(320, 240) as ctx:
+        ctx.set_option(ctx.OPT_HIST_VARIANT, variant)
+        ctx.set_option(ctx.OPT_WORKGROUPS, 64)
+        t = torch.zeros(30, 9, device="cuda")
+        idx, best = ctx.search_grid(dev(rs), dev(ws), t)
+    assert np.abs(t.cpu().numpy() - ro).max() <= SCORE_TOL
+    assert (idx, best) == (io, bo) or abs(float(ro.reshape(-1)[idx]) - float(bo)) <= 2e-7

@@ -44,7 +44,8 @@ def main():
         datasets["constant"] = (np.full((S, H, W), 255, np.uint8), np.zeros((Wn, H, W), np.uint8))
     dev = {k: (torch.from_numpy(r).cuda(), torch.from_numpy(w).cuda()) for k, (r, w) in datasets.items()}
 
-    variants = [("hist1 full", 1, 3), ("hist2 full", 2, 3), ("hist3 full", 3, 3), ("hist3 full noflat", 3, 7),
+    variants = [("hist1 full", 1, 3), ("hist2 full", 2, 3), ("hist3 full", 3, 3), ("hist4 pipelined", 4, 3), ("ws hist+drain", 4, 1), ("ws math+drain", 4, 2), ("ws hist only", 4, 5),
+                ("ws math only", 4, 6), ("ws drain only", 4, 0), ("ws empty", 4, 4),
                 ("hist1 hist-only", 1, 1), ("hist2 hist-only", 2, 1),
                 ("decode-only", 3, 2), ("empty loop", 3, 0)]
     ctx = nmi.NmiContext(W, H)
