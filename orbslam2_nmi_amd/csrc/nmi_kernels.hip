@@ -254,26 +254,33 @@ __device__ __forceinline__ void histogram_phase(Lds &lds, int par, const GridArg
             const int y = (a.chunks_per_row == 1) ? ch : (int)__umulhi((uint32_t)ch, a.cpr_magic);
             return (a.height - 1 - y) * a.chunks_per_row + (ch - y * a.chunks_per_row);
         };
-        // Software pipeline with two named register sets: the loads of the chunk after next are in flight while
-        // the current chunk's 16 atomics issue.  Loads are unconditional (index clamped to the last chunk, a valid
-        // address) so the code is straight-line and the compiler can wait on exact load counts; only the atomics
-        // are predicated on the chunk being in range.
+        // Software pipeline with three named register sets: the loads of the next two chunks are in flight while the
+        // current chunk's 16 atomics issue (one chunk ahead does not cover the L2-miss latency when fewer wavefronts
+        // share the LDS).  Loads are unconditional (index clamped to the last chunk, a valid address) so the code is
+        // straight-line and the compiler can wait on exact load counts; only the atomics are predicated on the chunk
+        // being in range.
         const bool try_flat = !(a.phase_mask & 4);  // ablation switch for the flat-chunk shortcut
         const int last = nchunks - 1;
         const int iters = (nchunks + NT - 1) / NT;  // workgroup-uniform
         int ch = tid;
-        int c0 = min(ch, last);
-        uint4 wa = wp[c0], ra = rp[render_chunk(c0)], wb, rb;
-        for (int it = 0; it < iters; it += 2) {
-            const int c1 = min(ch + NT, last);
-            wb = wp[c1];
-            rb = rp[render_chunk(c1)];
-            if (ch < nchunks) add_chunk<BG, SHIFTED, HIST>(lds, par, ra, wa, a.shift, try_flat);
+        const int c0 = min(ch, last), c1 = min(ch + NT, last);
+        uint4 wa = wp[c0], ra = rp[render_chunk(c0)];
+        uint4 wb = wp[c1], rb = rp[render_chunk(c1)];
+        uint4 wc, rc;
+        for (int it = 0; it < iters; it += 3) {
             const int c2 = min(ch + 2 * NT, last);
-            wa = wp[c2];
-            ra = rp[render_chunk(c2)];
+            wc = wp[c2];
+            rc = rp[render_chunk(c2)];
+            if (ch < nchunks) add_chunk<BG, SHIFTED, HIST>(lds, par, ra, wa, a.shift, try_flat);
+            const int c3 = min(ch + 3 * NT, last);
+            wa = wp[c3];
+            ra = rp[render_chunk(c3)];
             if (ch + NT < nchunks) add_chunk<BG, SHIFTED, HIST>(lds, par, rb, wb, a.shift, try_flat);
-            ch += 2 * NT;
+            const int c4 = min(ch + 4 * NT, last);
+            wb = wp[c4];
+            rb = rp[render_chunk(c4)];
+            if (ch + 2 * NT < nchunks) add_chunk<BG, SHIFTED, HIST>(lds, par, rc, wc, a.shift, try_flat);
+            ch += 3 * NT;
         }
     } else {
         // Any width / alignment: byte loads, position arithmetic as written in NMI.cu:79-83.
@@ -465,6 +472,29 @@ __device__ __forceinline__ void final_phase(Lds &lds, const GridArgs &a, int lan
     }
 }
 
+// One candidate start to finish on the exact path (returning atomics + wrap bookkeeping + flat-region folding), all 16
+// wavefronts.  It runs only for candidates with a bin above 65535 hits; the kernels call it from a separate cold loop
+// AFTER their hot loop, never inside it: inlined into the hot loop it cost ~10 % there (spills, code size), and as a
+// real function call inside the loop ~25 %.  Uses the parity-0 event list / total and leaves them, hist_warped and
+// the joint counters zero.
+template <bool SHIFTED>
+__device__ __forceinline__ void exact_candidate(Lds &lds, const GridArgs &a, int tid, int p, unsigned long long &prev_key)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const int w = p / a.S_local, s = p - w * a.S_local;
+    __syncthreads();  // wavefront 0 may still be finishing the previous candidate's final phase (it resets shared state)
+    histogram_phase<true, SHIFTED, 1, kBlock>(lds, 0, a, a.render_stack + (size_t)s * a.npix, a.warp_stack + (size_t)w * a.npix, tid);
+    __syncthreads();
+    decode_phase(lds, 0, a, wave, lane);
+    __syncthreads();
+    if (wave == 0) {
+        final_phase(lds, a, lane, p, w, s, prev_key);
+        for (int t = lane; t < kBins; t += 64) lds.hist_warped[t] = 0;
+        if (lane == 0) lds.ovf_n[0] = lds.total[0] = 0;
+    }
+    __syncthreads();
+}
+
 }  // namespace
 
 // One workgroup per candidate (grid-stride over the candidates of this launch).
@@ -505,7 +535,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
     if (tid < kBins) lds.hist_warped[tid] = 0;
     if (tid < 2) lds.ovf_n[tid] = lds.total[tid] = 0;
     bool table_pending = true;
-    bool degenerate = false;  // workgroup-uniform
+    int exact_from = -1;  // first candidate of this workgroup that needs the exact path (workgroup-uniform)
     __syncthreads();
 
     const int total = a.S_local * a.Wn;
@@ -517,13 +547,8 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
         const uint8_t *render = a.render_stack + (size_t)s * a.npix;
         const uint8_t *warped = a.warp_stack + (size_t)w * a.npix;
 
-        // A workgroup that has met a candidate with wrapped counters expects more of them (same frame, same renders)
-        // and goes straight to the exact path, which also folds flat regions.
-        const bool exact_first = kOptimistic && degenerate;
         if (a.phase_mask & 1) {
-            if (exact_first)
-                histogram_phase<BG, SHIFTED, 1, kBlock>(lds, par, a, render, warped, tid);
-            else if (a.phase_mask & 8) {  // ablation: only half of the wavefronts take part in the histogram phase
+            if (a.phase_mask & 8) {  // ablation: only half of the wavefronts take part in the histogram phase
                 if (wave < kWaves / 2) histogram_phase<BG, SHIFTED, kFirst, kBlock / 2>(lds, par, a, render, warped, tid);
             } else
                 histogram_phase<BG, SHIFTED, kFirst, kBlock>(lds, par, a, render, warped, tid);
@@ -536,17 +561,11 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
         __syncthreads();  // B1
         if (a.phase_mask & 2) decode_phase(lds, par, a, wave, lane);
         __syncthreads();  // B2
-        if (kOptimistic && !exact_first && (a.phase_mask & 3) == 3 && lds.total[par] != (uint32_t)a.npix) {
-            // Some counter wrapped (workgroup-uniform, rare): redo this candidate exactly.
-            degenerate = true;
-            __syncthreads();
-            if (tid < kBins) lds.hist_warped[tid] = 0;
-            if (tid == 0) lds.total[par] = 0;
-            __syncthreads();
-            histogram_phase<BG, SHIFTED, 1, kBlock>(lds, par, a, render, warped, tid);
-            __syncthreads();
-            decode_phase(lds, par, a, wave, lane);
-            __syncthreads();
+        if (kOptimistic && (a.phase_mask & 3) == 3 && lds.total[par] != (uint32_t)a.npix) {
+            // Some counter wrapped (workgroup-uniform, rare).  This candidate and, since the same frame and renders
+            // come back, all later ones of this workgroup are scored on the exact path in the cold loop below.
+            exact_from = p;
+            break;
         }
         if (wave == 0) {
             if (a.phase_mask & 2) final_phase(lds, a, lane, p, w, s, prev_key);
@@ -556,6 +575,14 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
                 lds.total[par ^ 1] = 0;   // read by everyone right after the previous B2; next candidate adds to it
             }
         }
+    }
+
+    if (kOptimistic && exact_from >= 0) {
+        __syncthreads();  // everyone has read the failed total; wavefront 0 is past the previous candidate's final phase
+        if (tid < kBins) lds.hist_warped[tid] = 0;
+        if (tid < 2) lds.total[tid] = lds.ovf_n[tid] = 0;
+        __syncthreads();
+        for (int p = exact_from; p < total; p += gridDim.x) exact_candidate<SHIFTED>(lds, a, tid, p, prev_key);
     }
 
     // ---- completion: the last workgroup to finish publishes the winner -------------------------------------
@@ -695,24 +722,6 @@ __device__ __forceinline__ void decode_from_scratch(Lds &lds, const GridArgs &a,
     if (i == 0) atomicAdd(&lds.total[0], wave_total);
 }
 
-// One candidate start to finish on the exact path, all 16 wavefronts (the sequential kernel's loop body).
-template <bool SHIFTED>
-__device__ __noinline__ void exact_candidate(Lds &lds, const GridArgs &a, int tid, int p, unsigned long long &prev_key)
-{
-    const int lane = tid & 63, wave = tid >> 6;
-    const int w = p / a.S_local, s = p - w * a.S_local;
-    histogram_phase<true, SHIFTED, 1, kBlock>(lds, 0, a, a.render_stack + (size_t)s * a.npix, a.warp_stack + (size_t)w * a.npix, tid);
-    __syncthreads();
-    decode_phase(lds, 0, a, wave, lane);
-    __syncthreads();
-    if (wave == 0) {
-        final_phase(lds, a, lane, p, w, s, prev_key);
-        for (int t = lane; t < kBins; t += 64) lds.hist_warped[t] = 0;
-        if (lane == 0) lds.ovf_n[0] = lds.total[0] = 0;
-    }
-    __syncthreads();
-}
-
 }  // namespace
 
 template <bool SHIFTED>
@@ -797,14 +806,10 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel_ws(GridArgs
             }
             __syncthreads();
         }
-        // The exact path is a real call (keeps its registers out of the pipelined loops); it gets its own copy of the
-        // arguments so that the kernel's copy never has its address taken and stays in scalar registers.
-        GridArgs a_exact = a;
         const int nredo = (int)lds.redo_n;
         for (int e = 0; e < nredo; ++e)
-            exact_candidate<SHIFTED>(lds, a_exact, tid, (int)blockIdx.x + (int)lds.redo[e] * (int)gridDim.x, prev_key);
-        for (int kk = kd + 1; kk < n; ++kk)
-            exact_candidate<SHIFTED>(lds, a_exact, tid, (int)blockIdx.x + kk * (int)gridDim.x, prev_key);
+            exact_candidate<SHIFTED>(lds, a, tid, (int)blockIdx.x + (int)lds.redo[e] * (int)gridDim.x, prev_key);
+        for (int kk = kd + 1; kk < n; ++kk) exact_candidate<SHIFTED>(lds, a, tid, (int)blockIdx.x + kk * (int)gridDim.x, prev_key);
     }
 
     // completion: identical to the sequential kernel
