@@ -1,0 +1,19 @@
+#!/bin/bash
+# Collects the round's measurement artefacts on the GPU box into gpurun_out/<tag>/:
+#   bench.json (default bench line), bench_blocking.json, bench_stream.json, kernel trace summary, three PMC passes.
+# Usage (on the GPU box, from the repo root):  bash tools/collect_profiles.sh r01_final
+set -o pipefail
+TAG=${1:-profile}
+OUT=$PWD/gpurun_out/$TAG
+ROOT=$PWD
+mkdir -p "$OUT"
+python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" || exit 1
+python3 bench.py --blocking --no-cpu-baseline > "$OUT/bench_blocking.json" 2>> "$OUT/bench.err" || exit 1
+python3 bench.py --config stream > "$OUT/bench_stream.json" 2>> "$OUT/bench.err" || exit 1
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --steps 50 --warmup 5 --no-cpu-baseline > "$OUT/trace.log" 2>&1 || exit 1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" --steps 20 --warmup 2 --no-cpu-baseline > "$OUT/pmc_fetch.log" 2>&1 || exit 1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$ROOT/bench.py" --steps 20 --warmup 2 --no-cpu-baseline > "$OUT/pmc_write.log" 2>&1 || exit 1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d "$OUT/pmc_lds" -- python3 "$ROOT/bench.py" --steps 20 --warmup 2 --no-cpu-baseline > "$OUT/pmc_lds.log" 2>&1 || exit 1
+cd "$ROOT"
+python3 tools/summarize_profiles.py "$OUT"

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Condenses a tools/collect_profiles.sh output directory into the files that get committed under profiles/:
+kernel_stats.csv (rocprofv3 --stats), pmc_summary.json (per-launch means of the nmi_grid_kernel counters) and
+pmc_traffic.json (HBM-side bytes per launch with the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md)."""
+import csv, glob, json, os, shutil, statistics as st, sys
+
+out = sys.argv[1]
+summary = {}
+for name in ("pmc_fetch", "pmc_write", "pmc_lds"):
+    files = glob.glob(os.path.join(out, name, "*", "*_counter_collection.csv"))
+    if not files:
+        continue
+    rows = [r for r in csv.DictReader(open(files[0])) if "nmi_grid_kernel" in r["Kernel_Name"]]
+    by = {}
+    for r in rows:
+        by.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    for k, v in by.items():
+        summary[k] = {"mean": st.mean(v), "min": min(v), "max": max(v), "launches": len(v)}
+stats = glob.glob(os.path.join(out, "trace", "*", "*_kernel_stats.csv"))
+if stats:
+    shutil.copy(stats[0], os.path.join(out, "kernel_stats.csv"))
+    for r in csv.DictReader(open(stats[0])):
+        if "nmi_grid_kernel" in r["Name"]:
+            summary["kernel_trace"] = {"name": r["Name"], "calls": int(r["Calls"]), "average_ns": float(r["AverageNs"]),
+                                       "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])}
+json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
+if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
+    # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  On gfx950 FETCH_SIZE counts exactly half of the bytes of a wide
+    # (16 B/lane) coalesced read stream -- this kernel's loads -- so it is doubled; WRITE_SIZE is exact (MI355X_MICROARCH.md, HBM).
+    fetch = summary["FETCH_SIZE"]["mean"] * 1024 * 2
+    write = summary["WRITE_SIZE"]["mean"] * 1024
+    json.dump({"hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected_x2": fetch, "write_bytes": write,
+               "note": "L2-fabric side counters (TCC_EA0): Infinity-Cache hits are included, so this is an upper bound on HBM bytes",
+               "source": os.path.basename(out)}, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1)[:1500])
