@@ -197,6 +197,8 @@ int nmi_last_kernel_ms(nmi_ctx *ctx, float *h_ms);
 #define NMI_OPT_WORKGROUPS 3   /* workgroups per launch; 0 = one per compute unit (default) */
 #define NMI_OPT_RESULT_PATH 4  /* how the 8-byte winner reaches the host: 1 the kernel posts it to pinned host memory
                                   and the call polls it (default), 0 hipMemcpyAsync + hipStreamSynchronize */
+#define NMI_OPT_XCD_TILING 5   /* 1 (default): candidates are visited in (warp x render) tiles so that the 32 workgroups
+                                  of one XCD share ~12 images in its L2; 0: linear order.  Same results either way. */
 int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value);
 
 /* Introspection. */

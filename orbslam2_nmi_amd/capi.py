@@ -194,7 +194,7 @@ class NmiContext:
             raise ValueError("handle 0 is the legacy default stream; use a torch.cuda.Stream() (non-default) instead")
         self._check(self._lib.nmi_set_stream(self._h, C.c_void_p(stream_handle)), "nmi_set_stream")
 
-    OPT_HIST_VARIANT, OPT_PHASE_MASK, OPT_WORKGROUPS, OPT_RESULT_PATH = 1, 2, 3, 4
+    OPT_HIST_VARIANT, OPT_PHASE_MASK, OPT_WORKGROUPS, OPT_RESULT_PATH, OPT_XCD_TILING = 1, 2, 3, 4, 5
 
     def set_option(self, option, value):
         self._check(self._lib.nmi_set_option(self._h, int(option), int(value)), "nmi_set_option")

@@ -37,6 +37,11 @@ struct nmi_ctx {
     int result_path = 1;                   // 1 mailbox spin (default), 0 hipMemcpyAsync + stream sync
     bool posted = false;                   // the most recent launch posts to the mailbox
     float *d_pair_rating = nullptr;
+    int *d_order = nullptr;               // visiting order of the candidates (XCD-aware tiling), cached per grid shape
+    int *h_order = nullptr;
+    int64_t order_cap = 0;
+    int order_S = -1, order_Wn = -1;
+    int xcd_tiling = 1;                   // NMI_OPT_XCD_TILING
     uint32_t *d_scratch = nullptr;        // drained-counter slabs of the pipelined kernel
     int scratch_workgroups = 0;
     // inverse homographies for the warp producer: a small ring of (pinned staging, device copy, "copy consumed" event)
@@ -98,6 +103,37 @@ int ensure_ratings(nmi_ctx *ctx, int64_t n)
     return NMI_OK;
 }
 
+// Visiting order of the candidates of an S x Wn grid: tiles of kTileW warps x kTileS renders (32 candidates = the
+// 32 workgroups one XCD runs at a time), tile after tile; within a tile render-fastest.  Cached per grid shape.
+int ensure_order(nmi_ctx *ctx, int S, int Wn)
+{
+    if (!ctx->xcd_tiling) return NMI_OK;
+    if (ctx->order_S == S && ctx->order_Wn == Wn) return NMI_OK;
+    const int64_t total = (int64_t)S * Wn;
+    if (total > ctx->order_cap) {
+        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_order) NMI_HIP_TRY(ctx, hipFree(ctx->d_order));
+        if (ctx->h_order) NMI_HIP_TRY(ctx, hipHostFree(ctx->h_order));
+        ctx->d_order = ctx->h_order = nullptr;
+        ctx->order_cap = 0;
+        NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_order, (size_t)total * sizeof(int)));
+        NMI_HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_order, (size_t)total * sizeof(int), hipHostMallocDefault));
+        ctx->order_cap = total;
+    } else {
+        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the staging copy may still feed an earlier upload
+    }
+    const int tile_s = S >= 8 ? 8 : (S >= 4 ? 4 : (S >= 2 ? 2 : 1)), tile_w = 32 / tile_s;
+    int64_t o = 0;
+    for (int w0 = 0; w0 < Wn; w0 += tile_w)
+        for (int s0 = 0; s0 < S; s0 += tile_s)
+            for (int w = w0; w < w0 + tile_w && w < Wn; ++w)
+                for (int s = s0; s < s0 + tile_s && s < S; ++s) ctx->h_order[o++] = w * S + s;
+    NMI_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order, ctx->h_order, (size_t)total * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    ctx->order_S = S;
+    ctx->order_Wn = Wn;
+    return NMI_OK;
+}
+
 // Enqueues the grid kernel (one launch, nothing else).  No synchronisation.
 int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_offset, int S_total,
                  const uint8_t *warp_stack, int Wn, float *d_ratings, unsigned long long *out_key, bool post,
@@ -122,6 +158,12 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     a.flip = p.render_bottom_up ? 1 : 0;
     a.table = ctx->table;
     a.scratch = ctx->d_scratch;
+    a.order = nullptr;
+    if (ctx->xcd_tiling && (int64_t)S_local * Wn > 0) {
+        const int orc = ensure_order(ctx, S_local, Wn);
+        if (orc != NMI_OK) return orc;
+        a.order = ctx->d_order;
+    }
     a.ratings = d_ratings;
     a.key = ctx->d_keys + ctx->slot;
     a.reset_key = ctx->d_keys + (ctx->slot ^ 1);
@@ -162,6 +204,12 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
         NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_scratch, nmi::grid_kernel_scratch_bytes(alloc)));
         ctx->scratch_workgroups = alloc;
         a.scratch = ctx->d_scratch;
+    a.order = nullptr;
+    if (ctx->xcd_tiling && (int64_t)S_local * Wn > 0) {
+        const int orc = ensure_order(ctx, S_local, Wn);
+        if (orc != NMI_OK) return orc;
+        a.order = ctx->d_order;
+    }
     }
     if (ctx->profiling) NMI_HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     NMI_HIP_TRY(ctx, nmi::launch_grid(a, workgroups, p.use_bg != 0, ctx->stream));
@@ -340,6 +388,8 @@ int nmi_destroy(nmi_ctx *ctx)
     if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
     if (ctx->d_pair_rating) (void)hipFree(ctx->d_pair_rating);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_order) (void)hipFree(ctx->d_order);
+    if (ctx->h_order) (void)hipHostFree(ctx->h_order);
     for (int i = 0; i < nmi_ctx::kWarpRing; ++i) {
         if (ctx->d_warp_coeffs[i]) (void)hipFree(ctx->d_warp_coeffs[i]);
         if (ctx->h_warp_coeffs[i]) (void)hipHostFree(ctx->h_warp_coeffs[i]);
@@ -377,8 +427,12 @@ int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value)
         ctx->hist_variant = (int)value;
         return NMI_OK;
     case NMI_OPT_PHASE_MASK:
-        if (value < 0 || value > 15) return NMI_ERR_INVALID_ARGUMENT;
+        if (value < 0 || value > 31) return NMI_ERR_INVALID_ARGUMENT;
         ctx->phase_mask = (int)value;
+        return NMI_OK;
+    case NMI_OPT_XCD_TILING:
+        if (value < 0 || value > 1) return NMI_ERR_INVALID_ARGUMENT;
+        ctx->xcd_tiling = (int)value;
         return NMI_OK;
     case NMI_OPT_RESULT_PATH:
         if (value < 0 || value > 1) return NMI_ERR_INVALID_ARGUMENT;

@@ -30,6 +30,7 @@ struct GridArgs {
     int flip;                     // render stored bottom-up (NMI.cu:82)
     const float *table;           // [npix + 1] per-count entropy terms
     uint32_t *scratch;            // pipelined kernel: [workgroups][2][32768] drained packed counters
+    const int *order;             // [S_local * Wn] candidate visited at each ordinal (XCD-aware tiling), or nullptr = identity
     float *ratings;               // [Wn][S_local] or nullptr
     unsigned long long *key;      // packed arg-max slot of this launch (zero on entry)
     unsigned long long *reset_key;  // the slot of the next launch: cleared by this one (ping-pong), or nullptr

@@ -50,6 +50,13 @@ struct Lds {
     uint32_t redo[4];             // ordinals (within this workgroup) of candidates to score again exactly
 };
 
+// Candidate visited by workgroup `b` in its round `r`.  Workgroups are dealt to the 8 XCDs round-robin (b and b + 8
+// share an XCD and its L2), so the 32 workgroups of an XCD take 32 CONSECUTIVE ordinals of the visiting order, and the
+// host lays the order out in tiles of (few warps) x (few renders): an XCD's round then touches ~12 images (~3.6 MB at
+// 640x480, inside its 4 MiB L2) instead of ~29.  Placement is a speed matter only; any order gives the same results.
+__device__ __forceinline__ int slot_in_round(int b, int grid) { return (grid & 7) == 0 ? (b & 7) * (grid >> 3) + (b >> 3) : b; }
+__device__ __forceinline__ int candidate_at(const GridArgs &a, int ordinal) { return a.order ? a.order[ordinal] : ordinal; }
+
 // ---- cross-lane helpers (DPP within a row of 16 lanes: lane i receives lane i + N) -------------------
 template <int N>
 __device__ __forceinline__ float row_shl(float x)
@@ -528,13 +535,16 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
     if (tid < kBins) lds.hist_warped[tid] = 0;
     if (tid < 2) lds.ovf_n[tid] = lds.total[tid] = 0;
     bool table_pending = true;
-    int exact_from = -1;  // first candidate of this workgroup that needs the exact path (workgroup-uniform)
+    int exact_from = -1;  // first ordinal of this workgroup that needs the exact path (workgroup-uniform)
     __syncthreads();
 
     const int total = a.S_local * a.Wn;
     unsigned long long prev_key = 0;
     int par = 0;
-    for (int p = blockIdx.x; p < total; p += gridDim.x, par ^= 1) {
+    const int slot = slot_in_round(blockIdx.x, gridDim.x);
+    int ordinal = slot;  // this workgroup visits ordinals slot, slot + grid, slot + 2 grid, ...
+    for (; ordinal < total; ordinal += gridDim.x, par ^= 1) {
+        const int p = candidate_at(a, ordinal);
         const int w = p / a.S_local;
         const int s = p - w * a.S_local;
         const uint8_t *render = a.render_stack + (size_t)s * a.npix;
@@ -557,7 +567,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
         if (kOptimistic && (a.phase_mask & 3) == 3 && lds.total[par] != (uint32_t)a.npix) {
             // Some counter wrapped (workgroup-uniform, rare).  This candidate and, since the same frame and renders
             // come back, all later ones of this workgroup are scored on the exact path in the cold loop below.
-            exact_from = p;
+            exact_from = ordinal;
             break;
         }
         if (wave == 0) {
@@ -575,7 +585,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
         if (tid < kBins) lds.hist_warped[tid] = 0;
         if (tid < 2) lds.total[tid] = lds.ovf_n[tid] = 0;
         __syncthreads();
-        for (int p = exact_from; p < total; p += gridDim.x) exact_candidate<SHIFTED>(lds, a, tid, p, prev_key);
+        for (int o = exact_from; o < total; o += gridDim.x) exact_candidate<SHIFTED>(lds, a, tid, candidate_at(a, o), prev_key);
     }
 
     // ---- completion: the last workgroup to finish publishes the winner -------------------------------------
@@ -584,7 +594,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
     // so it is issued after they were performed; the workgroup that draws the last ticket therefore reads the
     // final key.  Nothing here needs a cache write-back: the key travels in atomics, and the mailbox is one
     // 8-byte store (key in bits 0..62, launch parity in bit 63 -- scores are non-negative floats, bit 63 is free).
-    if (tid == 0) {
+    if (tid == 0 && !(a.phase_mask & 16)) {  // bit 4: timing experiment without the completion protocol (no result)
         const unsigned int one = prev_key == ~0ull ? 2u : 1u;  // always 1 (a key never has all bits set)
         const unsigned int arrived = __hip_atomic_fetch_add(a.done, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (arrived == gridDim.x - 1) {
@@ -740,7 +750,8 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel_ws(GridArgs
     __syncthreads();
 
     const int total = a.S_local * a.Wn;
-    const int n = (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;  // candidates of this workgroup (>= 1)
+    const int slot = slot_in_round(blockIdx.x, gridDim.x);
+    const int n = slot < total ? (total - slot + (int)gridDim.x - 1) / (int)gridDim.x : 0;  // candidates of this workgroup
     unsigned long long prev_key = 0;
     // two slabs per workgroup, alternating by candidate: D reads slab (k-1)&1 while the drain of candidate k fills slab k&1
     uint32_t *const slab0 = a.scratch + (size_t)blockIdx.x * 2 * kWords;
@@ -748,7 +759,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel_ws(GridArgs
     int k = 0;        // stage: H works on candidate k, D on candidate k-1
     bool bail = false;
     for (; k <= n && !bail; ++k) {
-        const int p = (int)blockIdx.x + k * (int)gridDim.x;
+        const int p = k < n ? candidate_at(a, slot + k * (int)gridDim.x) : 0;
         if (is_hist) {
             if (k < n && (a.phase_mask & 1)) {
                 const int w = p / a.S_local, s = p - w * a.S_local;
@@ -762,7 +773,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel_ws(GridArgs
         if (k < n && !(a.phase_mask & 4)) drain_to_scratch(lds, slab0 + (k & 1) * kWords, wave, lane);
         if (is_hist) {
             if (wave == 0 && k > 0) {
-                const int pp = p - (int)gridDim.x, w = pp / a.S_local, s = pp - w * a.S_local;
+                const int pp = candidate_at(a, slot + (k - 1) * (int)gridDim.x), w = pp / a.S_local, s = pp - w * a.S_local;
                 if ((a.phase_mask & 7) == 3 && lds.total[0] != (uint32_t)a.npix) {
                     // a 16-bit counter wrapped in candidate k-1: hand it (and everything after it) to the exact path
                     if (lane == 0) {
@@ -788,7 +799,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel_ws(GridArgs
             if (!is_hist) decode_from_scratch(lds, a, slab0 + (kd & 1) * kWords, dwave, lane);
             __syncthreads();
             if (wave == 0) {
-                const int pp = (int)blockIdx.x + kd * (int)gridDim.x, w = pp / a.S_local, s = pp - w * a.S_local;
+                const int pp = candidate_at(a, slot + kd * (int)gridDim.x), w = pp / a.S_local, s = pp - w * a.S_local;
                 if (lds.total[0] != (uint32_t)a.npix) {
                     if (lane == 0) lds.redo[lds.redo_n++] = (uint32_t)kd;
                 } else {
@@ -801,8 +812,8 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel_ws(GridArgs
         }
         const int nredo = (int)lds.redo_n;
         for (int e = 0; e < nredo; ++e)
-            exact_candidate<SHIFTED>(lds, a, tid, (int)blockIdx.x + (int)lds.redo[e] * (int)gridDim.x, prev_key);
-        for (int kk = kd + 1; kk < n; ++kk) exact_candidate<SHIFTED>(lds, a, tid, (int)blockIdx.x + kk * (int)gridDim.x, prev_key);
+            exact_candidate<SHIFTED>(lds, a, tid, candidate_at(a, slot + (int)lds.redo[e] * (int)gridDim.x), prev_key);
+        for (int kk = kd + 1; kk < n; ++kk) exact_candidate<SHIFTED>(lds, a, tid, candidate_at(a, slot + kk * (int)gridDim.x), prev_key);
     }
 
     // completion: identical to the sequential kernel
