@@ -393,3 +393,33 @@ def test_kernel_variants_agree(nmi, variant):
         idx, best = ctx.search_grid(dev(rs), dev(ws), t)
     assert np.abs(t.cpu().numpy() - ro).max() <= SCORE_TOL
     assert (idx, best) == (io, bo) or abs(float(ro.reshape(-1)[idx]) - float(bo)) <= 2e-7
+
+
+def test_randomised_shapes_and_switches(nmi):
+    """Seeded sweep over frame shapes, switches and value distributions (includes flat regions, zeros, saturated pixels):
+    histograms bit-exact, score within tolerance, for every draw."""
+    from oracle import binding as oc
+    rng = np.random.default_rng(20260104)
+    for it in range(40):
+        w = int(rng.choice([16, 32, 48, 64, 80, 17, 33, 100, 129, 256, 320]))
+        h = int(rng.integers(1, 96))
+        kind = it % 5
+        if kind == 0:
+            r = rng.integers(0, 256, (h, w), dtype=np.uint8)
+            f = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        elif kind == 1:  # few levels -> heavy bins
+            r = (rng.integers(0, 3, (h, w)) * 127).astype(np.uint8)
+            f = (rng.integers(0, 2, (h, w)) * 255).astype(np.uint8)
+        elif kind == 2:  # piecewise flat with zero borders
+            r = np.full((h, w), 255, np.uint8)
+            r[h // 4:, w // 3:] = rng.integers(0, 256, (h - h // 4, w - w // 3), dtype=np.uint8)
+            f = np.zeros((h, w), np.uint8)
+            f[: max(1, h // 2)] = rng.integers(1, 256, (max(1, h // 2), w), dtype=np.uint8)
+        elif kind == 3:  # smooth ramp + noise
+            r = ((np.arange(w)[None, :] * 3 + np.arange(h)[:, None] * 2) % 256).astype(np.uint8)
+            f = np.clip(r.astype(int) + rng.integers(-4, 5, (h, w)), 0, 255).astype(np.uint8)
+        else:
+            r = rng.integers(0, 256, (h, w), dtype=np.uint8)
+            f = r.copy()
+        check_pair(nmi, oc, r, f, bins=int(rng.choice([256, 64])), mode=int(rng.integers(0, 2)),
+                   bg=bool(rng.integers(0, 2)), bu=bool(rng.integers(0, 2)))
