@@ -143,6 +143,26 @@ int nmi_warp_homographies(const double K[9], const int32_t num_warp_xyz[3], cons
 int nmi_warp_stack(nmi_ctx *ctx, const uint8_t *d_frame, const double *h_forward, int32_t Wn, uint8_t *d_warp_stack);
 
 /*
+ * Render-stack producer for coloured point clouds: replaces Rendering<4>::renderToTextureOnGPU
+ * (Thirdparty/Localization/rendering.hpp:530-630, nmi_prop_RENDER 4, shaders/ShadingWithColor.*) for S camera
+ * translations of one pose -- no OpenGL.  nmi_render_mvp builds Projection * glm::lookAt for one view exactly as
+ * rendering.hpp:196-202,547-553 (column-major float[16] like glm); nmi_render_points draws the cloud into
+ * d_render_stack [S][H][W] (uint8, bottom-up rows like the GL texture, background 255).  d_xyz: float [N][3] vertices
+ * (loadXYZ output, objloader.cpp:257-260), d_red: float [N] red colour component (objloader.cpp:261: file value / 256).
+ * Enqueued on the context's stream.  Parity with an OpenGL driver's rasteriser is unpinned (kernel comment).
+ */
+typedef struct nmi_render_params {
+    double fx, fy, cx, cy;  /* Camera.fx .. Camera.cy (localization.cpp:149-152) */
+    float near_plane;       /* NMI.Render.NearPlane */
+    float far_plane;        /* NMI.Render.FarPlane  */
+    float point_size;       /* NMI.Render.PointSize -> glPointSize (rendering.hpp:307) */
+} nmi_render_params;
+int nmi_render_mvp(const nmi_render_params *rp, const float cam_pos[3], const float cam_look_at[3], const float cam_up[3],
+                   const float translation[3], float out_mvp[16]);
+int nmi_render_points(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int64_t n_points, const float *h_mvps, int32_t S,
+                      float point_size, uint8_t *d_render_stack);
+
+/*
  * Streaming form (BASELINE.json config 5): keyframes / search levels whose render stacks arrive from host memory.
  * A stream owns `depth` device slots; nmi_stream_submit enqueues, without blocking,
  *   copy stream    : hipMemcpyAsync of the pinned host render stack [S][H][W] (and the frame [H][W], if given) into a slot

@@ -23,7 +23,7 @@ ERR_NOT_READY = -4
 # Every symbol include/nmi_hip.h declares; tests check that the library exports all of them.
 EXPORTED_SYMBOLS = (
     "nmi_params_default", "nmi_create", "nmi_destroy", "nmi_set_stream", "nmi_synchronize", "nmi_eval_pair", "nmi_eval_pair_debug",
-    "nmi_search_grid", "nmi_search_grid_shard", "nmi_warp_homographies", "nmi_warp_stack", "nmi_stream_create", "nmi_stream_destroy",
+    "nmi_search_grid", "nmi_search_grid_shard", "nmi_warp_homographies", "nmi_warp_stack", "nmi_render_mvp", "nmi_render_points", "nmi_stream_create", "nmi_stream_destroy",
     "nmi_stream_submit", "nmi_stream_wait", "nmi_key_pack", "nmi_key_unpack", "nmi_search_grid_rccl",
     "nmi_rccl_unique_id", "nmi_rccl_comm_init", "nmi_rccl_comm_destroy", "nmi_set_profiling", "nmi_last_kernel_ms",
     "nmi_set_option", "nmi_abi_version", "nmi_error_string", "nmi_last_error_detail", "nmi_get_info",
@@ -36,6 +36,11 @@ class NmiParams(C.Structure):
         ("use_bg", C.c_int32), ("render_bottom_up", C.c_int32), ("device", C.c_int32),
         ("max_candidates", C.c_int32), ("stream", C.c_void_p), ("reserved", C.c_int32 * 8),
     ]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("near_plane", C.c_float),
+                ("far_plane", C.c_float), ("point_size", C.c_float)]
 
 
 class NmiError(RuntimeError):
@@ -75,6 +80,8 @@ def load_library(build_if_missing=False):
     lib.nmi_search_grid_shard.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp, u64p]
     lib.nmi_warp_homographies.argtypes = [C.POINTER(C.c_double), C.POINTER(i32), f32p, C.POINTER(C.c_double)]
     lib.nmi_warp_stack.argtypes = [vp, vp, C.POINTER(C.c_double), i32, vp]
+    lib.nmi_render_mvp.argtypes = [C.POINTER(RenderParams), f32p, f32p, f32p, f32p, f32p]
+    lib.nmi_render_points.argtypes = [vp, vp, vp, C.c_int64, f32p, i32, C.c_float, vp]
     lib.nmi_stream_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
     lib.nmi_stream_destroy.argtypes = [vp]
     lib.nmi_stream_submit.argtypes = [vp, vp, i32, vp, C.POINTER(C.c_double), i32, i64p]
@@ -124,6 +131,16 @@ def warp_homographies(K, num_warp_xyz, step_rad_xyz):
     if rc != NMI_OK:
         raise NmiError(rc, "nmi_warp_homographies")
     return out
+
+
+def render_mvp(rp, cam_pos, cam_look_at, cam_up, translation):
+    """Projection * glm::lookAt(pos + t, look_at + t, up) as rendering.hpp:196-202,547-553 -> float32 [16], column-major."""
+    f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+    out = (C.c_float * 16)()
+    rc = load_library().nmi_render_mvp(C.byref(rp), f3(cam_pos), f3(cam_look_at), f3(cam_up), f3(translation), out)
+    if rc != NMI_OK:
+        raise NmiError(rc, "nmi_render_mvp")
+    return np.array(out, np.float32)
 
 
 def _dev_u8(t, ndim, what):
@@ -265,6 +282,26 @@ class NmiContext:
         torch.cuda.current_stream(self.device).synchronize()  # `out` / `frame` may come from torch's stream
         self._check(self._lib.nmi_warp_stack(self._h, f.data_ptr(), m.ctypes.data_as(C.POINTER(C.c_double)), wn,
                                              o.data_ptr()), "nmi_warp_stack")
+        if sync:
+            self.synchronize()
+        return out
+
+    def render_points(self, xyz, red, mvps, point_size, out=None, sync=True):
+        """Rendering<4>::renderToTextureOnGPU without OpenGL: device float32 xyz [N,3] + red [N], host MVPs [S,16]
+        (render_mvp) -> render stack [S,H,W] u8 on the device, bottom-up rows, background 255."""
+        import torch
+        for t, shape in ((xyz, 2), (red, 1)):
+            if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.dim() != shape:
+                raise TypeError("xyz must be a contiguous float32 device tensor [N,3], red one of [N]")
+        m = np.ascontiguousarray(mvps, np.float32).reshape(-1, 16)
+        S = m.shape[0]
+        if out is None:
+            out = torch.empty((S, self.height, self.width), dtype=torch.uint8, device=self.device)
+        o = self._stack(out, "out")
+        torch.cuda.current_stream(self.device).synchronize()
+        self._check(self._lib.nmi_render_points(self._h, xyz.data_ptr(), red.data_ptr(), xyz.shape[0],
+                                                m.ctypes.data_as(C.POINTER(C.c_float)), S, float(point_size), o.data_ptr()),
+                    "nmi_render_points")
         if sync:
             self.synchronize()
         return out

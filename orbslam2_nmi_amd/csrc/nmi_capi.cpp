@@ -42,6 +42,10 @@ struct nmi_ctx {
     int64_t order_cap = 0;
     int order_S = -1, order_Wn = -1;
     int xcd_tiling = 1;                   // NMI_OPT_XCD_TILING
+    uint32_t *d_zbuf = nullptr;           // depth|colour buffers of the point-cloud renderer, [S][H][W]
+    int64_t zbuf_cap = 0;
+    float *d_mvps = nullptr, *h_mvps = nullptr;
+    int mvps_cap = 0;
     uint32_t *d_scratch = nullptr;        // drained-counter slabs of the pipelined kernel
     int scratch_workgroups = 0;
     // inverse homographies for the warp producer: a small ring of (pinned staging, device copy, "copy consumed" event)
@@ -388,6 +392,9 @@ int nmi_destroy(nmi_ctx *ctx)
     if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
     if (ctx->d_pair_rating) (void)hipFree(ctx->d_pair_rating);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_zbuf) (void)hipFree(ctx->d_zbuf);
+    if (ctx->d_mvps) (void)hipFree(ctx->d_mvps);
+    if (ctx->h_mvps) (void)hipHostFree(ctx->h_mvps);
     if (ctx->d_order) (void)hipFree(ctx->d_order);
     if (ctx->h_order) (void)hipHostFree(ctx->h_order);
     for (int i = 0; i < nmi_ctx::kWarpRing; ++i) {
@@ -546,6 +553,83 @@ int nmi_warp_stack(nmi_ctx *ctx, const uint8_t *d_frame, const double *h_forward
     NMI_HIP_TRY(ctx, hipMemcpyAsync(d_coeffs, h_coeffs, (size_t)Wn * 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     NMI_HIP_TRY(ctx, nmi::launch_warp(d_frame, d_coeffs, d_warp_stack, ctx->params.width, ctx->params.height, Wn, ctx->stream));
     NMI_HIP_TRY(ctx, hipEventRecord(ctx->warp_ev[ring], ctx->stream));
+    return NMI_OK;
+}
+
+// Projection (rendering.hpp:196-202, glm columns) * glm::lookAt(pos + t, look_at + t, up) (rendering.hpp:547-553), fp32.
+int nmi_render_mvp(const nmi_render_params *rp, const float cam_pos[3], const float cam_look_at[3], const float cam_up[3],
+                   const float translation[3], float out[16])
+{
+    if (!rp || !cam_pos || !cam_look_at || !cam_up || !translation || !out) return NMI_ERR_INVALID_ARGUMENT;
+    const float eye[3] = {cam_pos[0] + translation[0], cam_pos[1] + translation[1], cam_pos[2] + translation[2]};
+    const float ctr[3] = {cam_look_at[0] + translation[0], cam_look_at[1] + translation[1], cam_look_at[2] + translation[2]};
+    float f[3] = {ctr[0] - eye[0], ctr[1] - eye[1], ctr[2] - eye[2]};
+    float len = sqrtf(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
+    if (!(len > 0.0f)) return NMI_ERR_INVALID_ARGUMENT;
+    for (float &v : f) v /= len;
+    float sv[3] = {f[1] * cam_up[2] - f[2] * cam_up[1], f[2] * cam_up[0] - f[0] * cam_up[2], f[0] * cam_up[1] - f[1] * cam_up[0]};
+    len = sqrtf(sv[0] * sv[0] + sv[1] * sv[1] + sv[2] * sv[2]);
+    if (!(len > 0.0f)) return NMI_ERR_INVALID_ARGUMENT;
+    for (float &v : sv) v /= len;
+    const float u[3] = {sv[1] * f[2] - sv[2] * f[1], sv[2] * f[0] - sv[0] * f[2], sv[0] * f[1] - sv[1] * f[0]};
+    // view matrix, column-major V[c*4 + r]
+    float V[16] = {sv[0], u[0], -f[0], 0, sv[1], u[1], -f[1], 0, sv[2], u[2], -f[2], 0, 0, 0, 0, 1};
+    V[12] = -(sv[0] * eye[0] + sv[1] * eye[1] + sv[2] * eye[2]);
+    V[13] = -(u[0] * eye[0] + u[1] * eye[1] + u[2] * eye[2]);
+    V[14] = f[0] * eye[0] + f[1] * eye[1] + f[2] * eye[2];
+    const double zn = rp->near_plane, zf = rp->far_plane;
+    float P[16] = {0};
+    P[0] = (float)(rp->fx / (-rp->cx));          // Projection[0] = (fx / -cx, 0, 0, 0)
+    P[5] = (float)(rp->fy / (-rp->cy));          // Projection[1] = (0, fy / -cy, 0, 0)
+    P[10] = (float)((zn + zf) / (zn - zf));      // Projection[2] = (0, 0, (zn+zf)/(zn-zf), -1)
+    P[11] = -1.0f;
+    P[14] = (float)(2 * zn * zf / (zn - zf));    // Projection[3] = (0, 0, 2 zn zf/(zn-zf), 0)
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) {
+            float acc = 0.0f;
+            for (int k = 0; k < 4; ++k) acc += P[k * 4 + r] * V[c * 4 + k];
+            out[c * 4 + r] = acc;
+        }
+    return NMI_OK;
+}
+
+int nmi_render_points(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int64_t n_points, const float *h_mvps, int32_t S,
+                      float point_size, uint8_t *d_render_stack)
+{
+    if (!ctx || !h_mvps || !d_render_stack || S <= 0 || n_points < 0 || (n_points > 0 && (!d_xyz || !d_red)))
+        return NMI_ERR_INVALID_ARGUMENT;
+    ctx->detail.clear();
+    DeviceGuard guard(ctx->device);
+    const int64_t need = (int64_t)S * ctx->npix;
+    if (need > ctx->zbuf_cap || S > ctx->mvps_cap) {
+        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (need > ctx->zbuf_cap) {
+            if (ctx->d_zbuf) NMI_HIP_TRY(ctx, hipFree(ctx->d_zbuf));
+            ctx->d_zbuf = nullptr;
+            ctx->zbuf_cap = 0;
+            NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_zbuf, (size_t)need * sizeof(uint32_t)));
+            ctx->zbuf_cap = need;
+        }
+        if (S > ctx->mvps_cap) {
+            if (ctx->d_mvps) NMI_HIP_TRY(ctx, hipFree(ctx->d_mvps));
+            if (ctx->h_mvps) NMI_HIP_TRY(ctx, hipHostFree(ctx->h_mvps));
+            ctx->d_mvps = ctx->h_mvps = nullptr;
+            ctx->mvps_cap = 0;
+            NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_mvps, (size_t)S * 16 * sizeof(float)));
+            NMI_HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_mvps, (size_t)S * 16 * sizeof(float), hipHostMallocDefault));
+            ctx->mvps_cap = S;
+        }
+    } else {
+        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the pinned matrix staging may still feed an earlier copy
+    }
+    memcpy(ctx->h_mvps, h_mvps, (size_t)S * 16 * sizeof(float));
+    NMI_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mvps, ctx->h_mvps, (size_t)S * 16 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    // glPointSize: non-antialiased points use the size rounded to the nearest integer, at least 1 (OpenGL 3.3, 3.4.1)
+    int size = (int)floorf(point_size + 0.5f);
+    if (size < 1) size = 1;
+    if (size > 64) size = 64;
+    NMI_HIP_TRY(ctx, nmi::launch_render_points(d_xyz, d_red, n_points, ctx->d_mvps, S, ctx->d_zbuf, d_render_stack, ctx->params.width,
+                                               ctx->params.height, size, ctx->stream));
     return NMI_OK;
 }
 

@@ -971,4 +971,84 @@ hipError_t launch_warp(const uint8_t *frame, const float *coeffs, uint8_t *out, 
     return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Render-stack producer for coloured point clouds: Rendering<4>::renderToTextureOnGPU,
+// Thirdparty/Localization/rendering.hpp:530-630 with shaders/ShadingWithColor.{vertex,fragment}shader --
+// glClearColor(1,1,1) (:533), gl_Position = MVP * vec4(p,1), GL_POINTS of glPointSize(PointSize) (:307), GL_DEPTH_TEST
+// with GL_LESS (:294-297), colour = vertex colour, only the red channel kept (GL_RED texture, :347).
+// The OpenGL rasteriser is not part of the reference tree; the rules below are the OpenGL 3.3 specification's for
+// non-antialiased points (centre clipped against the view volume; size rounded to an integer >= 1; odd sizes centred on
+// floor(x)+0.5, even sizes on floor(x+0.5); 24-bit depth) evaluated in fp32 -- parity with a GL driver is unpinned.
+// Depth test + colour write are one 32-bit atomicMin on (depth24 << 8 | red8); equal depths resolve to the darker
+// fragment (GL: the first drawn).  Rows are written bottom-up like a GL texture (what NMI.cu:82 flips back).
+__global__ __launch_bounds__(256) void nmi_zbuf_clear_kernel(uint32_t *zbuf, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) zbuf[i] = 0xFFFFFFFFu;
+}
+
+__global__ __launch_bounds__(256) void nmi_splat_kernel(const float *__restrict__ xyz, const float *__restrict__ red, long long npoints,
+                                                        const float *__restrict__ mvps, uint32_t *__restrict__ zbuf, int width,
+                                                        int height, int size)
+{
+    __shared__ float m[16];
+    const int s = blockIdx.y;
+    if (threadIdx.x < 16) m[threadIdx.x] = mvps[s * 16 + threadIdx.x];  // column-major like glm: m[c*4 + r]
+    __syncthreads();
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= npoints) return;
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    // glm mat4 * vec4: (m0*x + m1*y) + (m2*z + m3*1), component-wise
+    const float cx = (m[0] * x + m[4] * y) + (m[8] * z + m[12]);
+    const float cy = (m[1] * x + m[5] * y) + (m[9] * z + m[13]);
+    const float cz = (m[2] * x + m[6] * y) + (m[10] * z + m[14]);
+    const float cw = (m[3] * x + m[7] * y) + (m[11] * z + m[15]);
+    if (!(cw > 0.0f) || cx < -cw || cx > cw || cy < -cw || cy > cw || cz < -cw || cz > cw) return;  // point clipping
+    const float xw = (cx / cw * 0.5f + 0.5f) * (float)width;
+    const float yw = (cy / cw * 0.5f + 0.5f) * (float)height;
+    const float zw = cz / cw * 0.5f + 0.5f;
+    const uint32_t depth = (uint32_t)(zw * 16777215.0f + 0.5f);
+    const float r = red[i];
+    const uint32_t colour = (uint32_t)(fminf(fmaxf(r, 0.0f), 1.0f) * 255.0f + 0.5f);
+    const uint32_t frag = (depth << 8) | colour;
+    int x0, y0;
+    if (size & 1) {
+        x0 = (int)floorf(xw) - (size - 1) / 2;
+        y0 = (int)floorf(yw) - (size - 1) / 2;
+    } else {
+        x0 = (int)floorf(xw + 0.5f) - size / 2;
+        y0 = (int)floorf(yw + 0.5f) - size / 2;
+    }
+    uint32_t *img = zbuf + (size_t)s * width * height;
+    for (int dy = 0; dy < size; ++dy) {
+        const int py = y0 + dy;
+        if (py < 0 || py >= height) continue;
+        for (int dx = 0; dx < size; ++dx) {
+            const int px = x0 + dx;
+            if (px < 0 || px >= width) continue;
+            atomicMin(&img[(size_t)py * width + px], frag);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void nmi_zbuf_resolve_kernel(const uint32_t *__restrict__ zbuf, uint8_t *__restrict__ out, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (uint8_t)(zbuf[i] & 0xFFu);  // untouched pixels keep the clear colour 255
+}
+
+hipError_t launch_render_points(const float *xyz, const float *red, long long npoints, const float *mvps, int S, uint32_t *zbuf,
+                                uint8_t *out, int width, int height, int size, hipStream_t stream)
+{
+    const size_t n = (size_t)S * width * height;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(nmi_zbuf_clear_kernel, dim3(blocks), dim3(256), 0, stream, zbuf, n);
+    if (npoints > 0) {
+        dim3 grid((unsigned)((npoints + 255) / 256), (unsigned)S);
+        hipLaunchKernelGGL(nmi_splat_kernel, grid, dim3(256), 0, stream, xyz, red, npoints, mvps, zbuf, width, height, size);
+    }
+    hipLaunchKernelGGL(nmi_zbuf_resolve_kernel, dim3(blocks), dim3(256), 0, stream, zbuf, out, n);
+    return hipGetLastError();
+}
+
 }  // namespace nmi

@@ -1,0 +1,121 @@
+"""Point-cloud render-stack producer: host matrices vs a float64 model of rendering.hpp:196-202 /
+glm::lookAt (CPU), the HIP splat kernel vs the fp32 numpy restatement (GPU, bit-exact), and frame -> device renders ->
+search end to end.  Parity with an OpenGL driver is unpinned (oracle/render_oracle_np.py header)."""
+import numpy as np
+import pytest
+
+from orbslam2_nmi_amd import capi, synthetic as sy
+from orbslam2_nmi_amd import build as nmi_build
+from oracle import render_oracle_np as ro
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    nmi_build.build()
+
+
+def params(w, h, point_size=3.0, zn=5.0, zf=30.0):
+    K = sy.intrinsics(w, h)
+    return capi.RenderParams(fx=K[0, 0], fy=K[1, 1], cx=K[0, 2], cy=K[1, 2], near_plane=zn, far_plane=zf, point_size=point_size)
+
+
+def test_mvp_matches_float64_model():
+    rng = np.random.default_rng(0)
+    rp = params(640, 480)
+    for _ in range(20):
+        pos, tr = rng.uniform(-20, 20, 3), rng.uniform(-1, 1, 3)
+        d = rng.standard_normal(3)
+        d /= np.linalg.norm(d)
+        up = np.cross(d, rng.standard_normal(3))
+        got = capi.render_mvp(rp, pos, pos + d, up, tr).reshape(4, 4).T  # column-major -> conventional
+        exp = ro.projection(rp.fx, rp.fy, rp.cx, rp.cy, rp.near_plane, rp.far_plane) @ ro.look_at(pos + tr, pos + d + tr, up)
+        assert np.allclose(got, exp, rtol=2e-5, atol=2e-4)
+    # a point straight ahead at mid depth lands on the image centre in clip space
+    m = capi.render_mvp(rp, (0, 0, 0), (0, 0, 1), (0, -1, 0), (0, 0, 0)).reshape(4, 4).T
+    c = m @ np.array([0, 0, 10.0, 1.0])
+    assert abs(c[0]) < 1e-6 and abs(c[1]) < 1e-6 and c[3] == pytest.approx(10.0) and -c[3] < c[2] < c[3]
+
+
+def plane_cloud(w, h, depth=10.0, density=1.6, seed=3):
+    """A fronto-parallel textured plane in front of a camera at the origin looking along +z: one point per ~1/density px."""
+    B = sy.scene(2 * w, 2 * h, seed)
+    rp = params(w, h)
+    n_u, n_v = int(2 * w * density / 2), int(2 * h * density / 2)
+    u = np.linspace(-w, 2 * w, n_u)            # pixel-ish coordinates over an area larger than the frame
+    v = np.linspace(-h, 2 * h, n_v)
+    uu, vv = np.meshgrid(u, v)
+    X = (uu - rp.cx) / rp.fx * depth
+    Y = (vv - rp.cy) / rp.fy * depth
+    xyz = np.stack([X, Y, np.full_like(X, depth)], -1).reshape(-1, 3).astype(np.float32)
+    ti = np.clip(((uu + w) / 3 * 2).astype(int), 0, 2 * w - 1)
+    tj = np.clip(((vv + h) / 3 * 2).astype(int), 0, 2 * h - 1)
+    red = (B[tj, ti].astype(np.float32) / np.float32(256.0)).reshape(-1)   # objloader.cpp:261: colour / 256
+    return xyz, red, rp
+
+
+def test_twin_sanity_single_point():
+    rp = params(64, 48, point_size=3)
+    m = capi.render_mvp(rp, (0, 0, 0), (0, 0, 1), (0, -1, 0), (0, 0, 0))
+    img = ro.render_points(np.array([[0, 0, 10.0]], np.float32), np.array([100 / 256], np.float32), m, 64, 48, 3)
+    ys, xs = np.nonzero(img != 255)
+    assert len(ys) == 9 and img[ys[0], xs[0]] == 100                      # 3x3 sprite, colour round(100/256*255)
+    assert xs.min() == 31 and xs.max() == 33 and ys.min() == 23 and ys.max() == 25   # centred on the window centre
+    # behind the camera / beyond the far plane / outside the frustum: nothing drawn
+    for p in ([0, 0, -10.0], [0, 0, 40.0], [1000.0, 0, 10.0], [0, 0, 2.0]):
+        assert (ro.render_points(np.array([p], np.float32), np.array([0.5], np.float32), m, 64, 48, 3) == 255).all()
+    # depth test: the nearer point wins regardless of draw order
+    two = np.array([[0, 0, 20.0], [0, 0, 10.0]], np.float32)
+    for order in ([0, 1], [1, 0]):
+        img = ro.render_points(two[order], np.array([0.9, 0.1], np.float32)[order], m, 64, 48, 1)
+        assert img[24, 32] == int(0.1 * 255 + 0.5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("point_size", [1.0, 2.0, 3.0, 4.4])
+def test_gpu_splat_bit_exact_vs_twin(point_size):
+    torch = pytest.importorskip("torch")
+    import orbslam2_nmi_amd as nmi
+    w, h = 160, 120
+    xyz, red, rp = plane_cloud(w, h)
+    rng = np.random.default_rng(5)
+    extra = rng.uniform(-30, 30, (5000, 3)).astype(np.float32)          # clutter at random depths incl. behind / too near / too far
+    xyz = np.concatenate([xyz, extra])
+    red = np.concatenate([red, rng.uniform(-0.2, 1.2, 5000).astype(np.float32)])
+    mvps = np.stack([capi.render_mvp(rp, (0, 0, 0), (0, 0, 1), (0, -1, 0), t)
+                     for t in ((0, 0, 0), (0.3, -0.2, 0.5), (-1.0, 0.4, -2.0))])
+    with nmi.NmiContext(w, h) as ctx:
+        got = ctx.render_points(torch.from_numpy(xyz).cuda(), torch.from_numpy(red).cuda(), mvps, point_size).cpu().numpy()
+    exp = ro.render_stack(xyz, red, mvps, w, h, point_size)
+    assert got.shape == exp.shape == (3, h, w)
+    assert (got == exp).all(), f"{(got != exp).sum()} pixels differ"
+    assert (exp != 255).mean() > (0.25 if point_size < 2 else 0.6)        # the plane actually covers the view
+
+
+@pytest.mark.gpu
+def test_gpu_cloud_to_winner_end_to_end():
+    """cloud + pose -> device render stack for a 3x3x3 translation grid; frame = the view from a displaced pose; the
+    search must pick the cell nearest to the displacement (no OpenGL, no host-side rendering of the stack)."""
+    torch = pytest.importorskip("torch")
+    import orbslam2_nmi_amd as nmi
+    from orbslam2_nmi_amd import hostapi as H
+    w, h = 320, 240
+    xyz, red, rp = plane_cloud(w, h, density=2.0)
+    Twc = np.eye(4, dtype=np.float32)
+    Twc[:3, 1] = [0, -1, 0]                       # camera up = -y, view = +z (setupCam reads these columns, ioData.cpp:177-197)
+    grid = H.SearchKernel.make([3, 3, 3, 1, 1, 1], [0.2, 0.2, 0.5, 0.02, 0.02, 0.05])
+    pos, look, up = Twc[:3, 3], Twc[:3, 3] + Twc[:3, 2], Twc[:3, 1]
+    cells = [(sx, sy, sz) for sz in range(3) for sy in range(3) for sx in range(3)]
+    trans = [H.calculate_translation(Twc, grid, *c) for c in cells]
+    mvps = np.stack([capi.render_mvp(rp, pos, look, up, t) for t in trans])
+    truth_cell = (2, 0, 1)
+    t_true = H.calculate_translation(Twc, grid, *truth_cell) * np.float32(0.9)   # near, not on, that cell
+    with nmi.NmiContext(w, h) as ctx:
+        dx, dr = torch.from_numpy(xyz).cuda(), torch.from_numpy(red).cuda()
+        rs = ctx.render_points(dx, dr, mvps, 3.0)
+        frame = ctx.render_points(dx, torch.sqrt(dr), capi.render_mvp(rp, pos, look, up, t_true)[None], 3.0)  # other "modality"
+        fr = torch.flip(frame[0], dims=[0]).contiguous()       # the camera frame is top-down; renders are bottom-up
+        t = torch.zeros(1, 27, device="cuda")
+        idx, best = ctx.search_grid(rs, fr[None], t)
+    assert cells[idx] == truth_cell and best > 0.3
+    tab = t.cpu().numpy().reshape(-1)
+    assert best > 1.5 * np.sort(tab)[-2]
