@@ -119,9 +119,69 @@ def run_stream_config(args):
     ctx.close()
 
 
+def run_e2e_config(args):
+    """Everything on the device: coloured point cloud + camera frame in HBM; per keyframe 3 search levels, each level =
+    27 renders of the cloud (nmi_render_points) + 27 warps of the frame (nmi_warp_stack) + the 729-candidate search.
+    Only matrices cross PCIe.  Not the headline line (the render / warp producers are the section-8f rows)."""
+    import torch
+
+    import orbslam2_nmi_amd as nmi
+    from orbslam2_nmi_amd import capi, hostapi as H, synthetic as sy
+
+    w, h, levels = 848, 480, 3
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    K = sy.intrinsics(w, h)
+    rp = capi.RenderParams(fx=K[0, 0], fy=K[1, 1], cx=K[0, 2], cy=K[1, 2], near_plane=5.0, far_plane=30.0, point_size=3.0)
+    # a textured plane at 10 m, ~1.3 M points (about 2 per pixel of the view), plus the frame seen from a displaced pose
+    B = sy.scene(2 * w, 2 * h, 77)
+    nu, nv = int(3 * w * 0.9), int(3 * h * 0.9)
+    uu, vv = np.meshgrid(np.linspace(-w, 2 * w, nu), np.linspace(-h, 2 * h, nv))
+    xyz = np.stack([(uu - rp.cx) / rp.fx * 10.0, (vv - rp.cy) / rp.fy * 10.0, np.full_like(uu, 10.0)], -1).reshape(-1, 3).astype(np.float32)
+    red = (B[np.clip(((vv + h) / 3 * 2).astype(int), 0, 2 * h - 1), np.clip(((uu + w) / 3 * 2).astype(int), 0, 2 * w - 1)]
+           .astype(np.float32) / np.float32(256)).reshape(-1)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    dx, dr = torch.from_numpy(xyz).cuda(), torch.from_numpy(red).cuda()
+    ctx = nmi.NmiContext(w, h)
+    ctx.set_stream(stream.cuda_stream)
+    Twc = np.eye(4, dtype=np.float32)
+    Twc[:3, 1] = [0, -1, 0]
+    pos, look, up = Twc[:3, 3], Twc[:3, 3] + Twc[:3, 2], Twc[:3, 1]
+    grids = [H.SearchKernel.make([3] * 6, [s / 2 ** l for s in (0.2, 0.2, 0.5, 0.02, 0.02, 0.05)]) for l in range(levels)]
+    cells = [(sx, sy, sz) for sz in range(3) for sy in range(3) for sx in range(3)]
+    mvps = [np.stack([capi.render_mvp(rp, pos, look, up, H.calculate_translation(Twc, g, *c)) for c in cells]) for g in grids]
+    homs = [capi.warp_homographies(K, (3, 3, 3), tuple(g.step[3:6])) for g in grids]
+    frame = torch.flip(ctx.render_points(dx, torch.sqrt(dr), capi.render_mvp(rp, pos, look, up, (0, 0, 0))[None], 3.0)[0], dims=[0]).contiguous()
+    rs = torch.empty((27, h, w), dtype=torch.uint8, device="cuda")
+    ws = torch.empty((27, h, w), dtype=torch.uint8, device="cuda")
+
+    def keyframe():
+        out = None
+        for l in range(levels):
+            ctx.render_points(dx, dr, mvps[l], 3.0, out=rs, sync=False)
+            ctx.warp_stack(frame, homs[l], out=ws, sync=False)
+            out = ctx.search_grid(rs, ws)
+        return out
+
+    for _ in range(3):
+        res = keyframe()
+    if res[0] != 13 * 27 + 13:
+        sys.exit(f"e2e config: unexpected winner {res}")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.keyframes):
+        keyframe()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"metric": "keyframes/s (device end to end: 848x480, 3 levels x (27 cloud renders + 27 warps + 729-candidate search))",
+                      "value": args.keyframes / dt, "unit": "keyframes/s", "evals_per_s": args.keyframes * levels * 729 / dt,
+                      "n_gpus": 1, "points": int(xyz.shape[0]), "data": "synthetic", "ms_per_level": dt / args.keyframes / levels * 1e3}))
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", default="c2", choices=["c2", "stream"],
+    ap.add_argument("--config", default="c2", choices=["c2", "stream", "e2e"],
                     help="c2 = BASELINE.json configs[1] (the headline line); stream = configs[4] shape on the local GPU")
     ap.add_argument("--keyframes", type=int, default=100)
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,6 +197,8 @@ def main():
     args = ap.parse_args()
     if args.config == "stream":
         return run_stream_config(args)
+    if args.config == "e2e":
+        return run_e2e_config(args)
 
     import torch
 

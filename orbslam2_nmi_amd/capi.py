@@ -210,6 +210,15 @@ class NmiContext:
         if stream_handle == 0:
             raise ValueError("handle 0 is the legacy default stream; use a torch.cuda.Stream() (non-default) instead")
         self._check(self._lib.nmi_set_stream(self._h, C.c_void_p(stream_handle)), "nmi_set_stream")
+        self._bound_stream = stream_handle
+
+    def _order_after_torch(self):
+        """Inputs produced by torch ops must be complete before this context's stream reads them: nothing to do when
+        the context runs on torch's current stream, otherwise wait for that stream."""
+        import torch
+        cur = torch.cuda.current_stream(self.device)
+        if getattr(self, "_bound_stream", None) != cur.cuda_stream:
+            cur.synchronize()
 
     OPT_HIST_VARIANT, OPT_PHASE_MASK, OPT_WORKGROUPS, OPT_RESULT_PATH, OPT_XCD_TILING = 1, 2, 3, 4, 5
 
@@ -279,7 +288,7 @@ class NmiContext:
         o = self._stack(out, "out")
         if o.shape[0] != wn:
             raise ValueError("out has the wrong number of warps")
-        torch.cuda.current_stream(self.device).synchronize()  # `out` / `frame` may come from torch's stream
+        self._order_after_torch()  # `out` / `frame` may come from torch's stream
         self._check(self._lib.nmi_warp_stack(self._h, f.data_ptr(), m.ctypes.data_as(C.POINTER(C.c_double)), wn,
                                              o.data_ptr()), "nmi_warp_stack")
         if sync:
@@ -298,7 +307,7 @@ class NmiContext:
         if out is None:
             out = torch.empty((S, self.height, self.width), dtype=torch.uint8, device=self.device)
         o = self._stack(out, "out")
-        torch.cuda.current_stream(self.device).synchronize()
+        self._order_after_torch()
         self._check(self._lib.nmi_render_points(self._h, xyz.data_ptr(), red.data_ptr(), xyz.shape[0],
                                                 m.ctypes.data_as(C.POINTER(C.c_float)), S, float(point_size), o.data_ptr()),
                     "nmi_render_points")

@@ -16,6 +16,17 @@
 #include "nmi_hip.h"
 #include "nmi_kernels.h"
 
+// Small host->device parameter uploads (warp coefficients, view matrices) go through a ring of pinned staging buffers so
+// that back-to-back submissions never have to wait for the stream: entry i is reused only after the copy that read it.
+struct StagingRing {
+    static constexpr int kSlots = 4;
+    float *h[kSlots] = {};
+    float *d[kSlots] = {};
+    hipEvent_t ev[kSlots] = {};
+    size_t cap = 0;  // floats per slot
+    unsigned uses = 0;
+};
+
 struct nmi_ctx {
     nmi_params params{};
     int device = 0;
@@ -42,10 +53,9 @@ struct nmi_ctx {
     int64_t order_cap = 0;
     int order_S = -1, order_Wn = -1;
     int xcd_tiling = 1;                   // NMI_OPT_XCD_TILING
-    uint32_t *d_zbuf = nullptr;           // depth|colour buffers of the point-cloud renderer, [S][H][W]
+    uint32_t *d_zbuf = nullptr;           // depth|colour anchor buffers of the point-cloud renderer (padded, per view)
     int64_t zbuf_cap = 0;
-    float *d_mvps = nullptr, *h_mvps = nullptr;
-    int mvps_cap = 0;
+    StagingRing mvp_ring;
     uint32_t *d_scratch = nullptr;        // drained-counter slabs of the pipelined kernel
     int scratch_workgroups = 0;
     // inverse homographies for the warp producer: a small ring of (pinned staging, device copy, "copy consumed" event)
@@ -393,8 +403,11 @@ int nmi_destroy(nmi_ctx *ctx)
     if (ctx->d_pair_rating) (void)hipFree(ctx->d_pair_rating);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_zbuf) (void)hipFree(ctx->d_zbuf);
-    if (ctx->d_mvps) (void)hipFree(ctx->d_mvps);
-    if (ctx->h_mvps) (void)hipHostFree(ctx->h_mvps);
+    for (int i = 0; i < StagingRing::kSlots; ++i) {
+        if (ctx->mvp_ring.d[i]) (void)hipFree(ctx->mvp_ring.d[i]);
+        if (ctx->mvp_ring.h[i]) (void)hipHostFree(ctx->mvp_ring.h[i]);
+        if (ctx->mvp_ring.ev[i]) (void)hipEventDestroy(ctx->mvp_ring.ev[i]);
+    }
     if (ctx->d_order) (void)hipFree(ctx->d_order);
     if (ctx->h_order) (void)hipHostFree(ctx->h_order);
     for (int i = 0; i < nmi_ctx::kWarpRing; ++i) {
@@ -600,35 +613,41 @@ int nmi_render_points(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int6
         return NMI_ERR_INVALID_ARGUMENT;
     ctx->detail.clear();
     DeviceGuard guard(ctx->device);
-    const int64_t need = (int64_t)S * ctx->npix;
-    if (need > ctx->zbuf_cap || S > ctx->mvps_cap) {
-        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (need > ctx->zbuf_cap) {
-            if (ctx->d_zbuf) NMI_HIP_TRY(ctx, hipFree(ctx->d_zbuf));
-            ctx->d_zbuf = nullptr;
-            ctx->zbuf_cap = 0;
-            NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_zbuf, (size_t)need * sizeof(uint32_t)));
-            ctx->zbuf_cap = need;
-        }
-        if (S > ctx->mvps_cap) {
-            if (ctx->d_mvps) NMI_HIP_TRY(ctx, hipFree(ctx->d_mvps));
-            if (ctx->h_mvps) NMI_HIP_TRY(ctx, hipHostFree(ctx->h_mvps));
-            ctx->d_mvps = ctx->h_mvps = nullptr;
-            ctx->mvps_cap = 0;
-            NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_mvps, (size_t)S * 16 * sizeof(float)));
-            NMI_HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_mvps, (size_t)S * 16 * sizeof(float), hipHostMallocDefault));
-            ctx->mvps_cap = S;
-        }
-    } else {
-        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the pinned matrix staging may still feed an earlier copy
-    }
-    memcpy(ctx->h_mvps, h_mvps, (size_t)S * 16 * sizeof(float));
-    NMI_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mvps, ctx->h_mvps, (size_t)S * 16 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     // glPointSize: non-antialiased points use the size rounded to the nearest integer, at least 1 (OpenGL 3.3, 3.4.1)
     int size = (int)floorf(point_size + 0.5f);
     if (size < 1) size = 1;
     if (size > 64) size = 64;
-    NMI_HIP_TRY(ctx, nmi::launch_render_points(d_xyz, d_red, n_points, ctx->d_mvps, S, ctx->d_zbuf, d_render_stack, ctx->params.width,
+    const int64_t need = (int64_t)nmi::render_zbuf_words(S, ctx->params.width, ctx->params.height, size);
+    if (need > ctx->zbuf_cap) {
+        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_zbuf) NMI_HIP_TRY(ctx, hipFree(ctx->d_zbuf));
+        ctx->d_zbuf = nullptr;
+        ctx->zbuf_cap = 0;
+        NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_zbuf, (size_t)need * sizeof(uint32_t)));
+        ctx->zbuf_cap = need;
+    }
+    StagingRing &ring = ctx->mvp_ring;
+    if ((size_t)S * 16 > ring.cap) {
+        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < StagingRing::kSlots; ++i) {
+            if (ring.d[i]) NMI_HIP_TRY(ctx, hipFree(ring.d[i]));
+            if (ring.h[i]) NMI_HIP_TRY(ctx, hipHostFree(ring.h[i]));
+            ring.d[i] = ring.h[i] = nullptr;
+        }
+        ring.cap = 0;
+        for (int i = 0; i < StagingRing::kSlots; ++i) {
+            NMI_HIP_TRY(ctx, hipMalloc((void **)&ring.d[i], (size_t)S * 16 * sizeof(float)));
+            NMI_HIP_TRY(ctx, hipHostMalloc((void **)&ring.h[i], (size_t)S * 16 * sizeof(float), hipHostMallocDefault));
+            if (!ring.ev[i]) NMI_HIP_TRY(ctx, hipEventCreateWithFlags(&ring.ev[i], hipEventDisableTiming));
+        }
+        ring.cap = (size_t)S * 16;
+    }
+    const int slot = (int)(ring.uses++ % StagingRing::kSlots);
+    NMI_HIP_TRY(ctx, hipEventSynchronize(ring.ev[slot]));
+    memcpy(ring.h[slot], h_mvps, (size_t)S * 16 * sizeof(float));
+    NMI_HIP_TRY(ctx, hipMemcpyAsync(ring.d[slot], ring.h[slot], (size_t)S * 16 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    NMI_HIP_TRY(ctx, hipEventRecord(ring.ev[slot], ctx->stream));
+    NMI_HIP_TRY(ctx, nmi::launch_render_points(d_xyz, d_red, n_points, ring.d[slot], S, ctx->d_zbuf, d_render_stack, ctx->params.width,
                                                ctx->params.height, size, ctx->stream));
     return NMI_OK;
 }

@@ -987,67 +987,87 @@ __global__ __launch_bounds__(256) void nmi_zbuf_clear_kernel(uint32_t *zbuf, siz
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) zbuf[i] = 0xFFFFFFFFu;
 }
 
+// One lane per point, looping over the S views: the cloud is read once, not once per view (27 views of a 3 M-point
+// cloud would otherwise stream 1.3 GB per level); the S matrices sit in LDS.
+constexpr int kMaxViewsPerLaunch = 64;
+
 __global__ __launch_bounds__(256) void nmi_splat_kernel(const float *__restrict__ xyz, const float *__restrict__ red, long long npoints,
-                                                        const float *__restrict__ mvps, uint32_t *__restrict__ zbuf, int width,
-                                                        int height, int size)
+                                                        const float *__restrict__ mvps, int views, uint32_t *__restrict__ zbuf,
+                                                        int width, int height, int size)
 {
-    __shared__ float m[16];
-    const int s = blockIdx.y;
-    if (threadIdx.x < 16) m[threadIdx.x] = mvps[s * 16 + threadIdx.x];  // column-major like glm: m[c*4 + r]
+    __shared__ float m_all[kMaxViewsPerLaunch * 16];
+    for (int t = threadIdx.x; t < views * 16; t += blockDim.x) m_all[t] = mvps[t];  // column-major like glm: m[c*4 + r]
     __syncthreads();
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (i >= npoints) return;
     const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-    // glm mat4 * vec4: (m0*x + m1*y) + (m2*z + m3*1), component-wise
-    const float cx = (m[0] * x + m[4] * y) + (m[8] * z + m[12]);
-    const float cy = (m[1] * x + m[5] * y) + (m[9] * z + m[13]);
-    const float cz = (m[2] * x + m[6] * y) + (m[10] * z + m[14]);
-    const float cw = (m[3] * x + m[7] * y) + (m[11] * z + m[15]);
-    if (!(cw > 0.0f) || cx < -cw || cx > cw || cy < -cw || cy > cw || cz < -cw || cz > cw) return;  // point clipping
-    const float xw = (cx / cw * 0.5f + 0.5f) * (float)width;
-    const float yw = (cy / cw * 0.5f + 0.5f) * (float)height;
-    const float zw = cz / cw * 0.5f + 0.5f;
-    const uint32_t depth = (uint32_t)(zw * 16777215.0f + 0.5f);
     const float r = red[i];
     const uint32_t colour = (uint32_t)(fminf(fmaxf(r, 0.0f), 1.0f) * 255.0f + 0.5f);
-    const uint32_t frag = (depth << 8) | colour;
-    int x0, y0;
-    if (size & 1) {
-        x0 = (int)floorf(xw) - (size - 1) / 2;
-        y0 = (int)floorf(yw) - (size - 1) / 2;
-    } else {
-        x0 = (int)floorf(xw + 0.5f) - size / 2;
-        y0 = (int)floorf(yw + 0.5f) - size / 2;
-    }
-    uint32_t *img = zbuf + (size_t)s * width * height;
-    for (int dy = 0; dy < size; ++dy) {
-        const int py = y0 + dy;
-        if (py < 0 || py >= height) continue;
-        for (int dx = 0; dx < size; ++dx) {
-            const int px = x0 + dx;
-            if (px < 0 || px >= width) continue;
-            atomicMin(&img[(size_t)py * width + px], frag);
+    for (int s = 0; s < views; ++s) {
+        const float *m = m_all + s * 16;
+        // glm mat4 * vec4: (m0*x + m1*y) + (m2*z + m3*1), component-wise
+        const float cx = (m[0] * x + m[4] * y) + (m[8] * z + m[12]);
+        const float cy = (m[1] * x + m[5] * y) + (m[9] * z + m[13]);
+        const float cz = (m[2] * x + m[6] * y) + (m[10] * z + m[14]);
+        const float cw = (m[3] * x + m[7] * y) + (m[11] * z + m[15]);
+        if (!(cw > 0.0f) || cx < -cw || cx > cw || cy < -cw || cy > cw || cz < -cw || cz > cw) continue;  // point clipping
+        const float xw = (cx / cw * 0.5f + 0.5f) * (float)width;
+        const float yw = (cy / cw * 0.5f + 0.5f) * (float)height;
+        const float zw = cz / cw * 0.5f + 0.5f;
+        const uint32_t depth = (uint32_t)(zw * 16777215.0f + 0.5f);
+        const uint32_t frag = (depth << 8) | colour;
+        int x0, y0;
+        if (size & 1) {
+            x0 = (int)floorf(xw) - (size - 1) / 2;
+            y0 = (int)floorf(yw) - (size - 1) / 2;
+        } else {
+            x0 = (int)floorf(xw + 0.5f) - size / 2;
+            y0 = (int)floorf(yw + 0.5f) - size / 2;
         }
+        // Only the sprite's anchor (its lowest-left pixel) is written here: one atomic per point and view instead of
+        // size^2.  Two points with the same anchor have the same footprint, so the farther one would lose on every
+        // pixel anyway; the resolve pass below takes, for each pixel, the minimum over the size^2 anchors whose
+        // sprites cover it -- exactly the depth-tested sprites.  The buffer is padded by size-1 so that sprites
+        // straddling the left / bottom edge keep their anchor.
+        const int ax = x0 + size - 1, ay = y0 + size - 1, wp = width + size - 1, hp = height + size - 1;
+        if (ax < 0 || ax >= wp || ay < 0 || ay >= hp) continue;
+        atomicMin(&zbuf[(size_t)s * wp * hp + (size_t)ay * wp + ax], frag);
     }
 }
 
-__global__ __launch_bounds__(256) void nmi_zbuf_resolve_kernel(const uint32_t *__restrict__ zbuf, uint8_t *__restrict__ out, size_t n)
+__global__ __launch_bounds__(256) void nmi_zbuf_resolve_kernel(const uint32_t *__restrict__ zbuf, uint8_t *__restrict__ out, int views,
+                                                               int width, int height, int size)
 {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = (uint8_t)(zbuf[i] & 0xFFu);  // untouched pixels keep the clear colour 255
+    const int wp = width + size - 1, hp = height + size - 1;
+    const size_t n = (size_t)views * width * height;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int px = (int)(i % width), py = (int)((i / width) % height), s = (int)(i / ((size_t)width * height));
+        const uint32_t *base = zbuf + (size_t)s * wp * hp + (size_t)py * wp + px;
+        uint32_t best = 0xFFFFFFFFu;
+        for (int dy = 0; dy < size; ++dy)
+            for (int dx = 0; dx < size; ++dx) best = min(best, base[(size_t)dy * wp + dx]);
+        out[i] = (uint8_t)(best & 0xFFu);  // untouched pixels keep the clear colour 255
+    }
 }
+
+size_t render_zbuf_words(int S, int width, int height, int size) { return (size_t)S * (width + size - 1) * (height + size - 1); }
 
 hipError_t launch_render_points(const float *xyz, const float *red, long long npoints, const float *mvps, int S, uint32_t *zbuf,
                                 uint8_t *out, int width, int height, int size, hipStream_t stream)
 {
+    const size_t nz = render_zbuf_words(S, width, height, size);
     const size_t n = (size_t)S * width * height;
-    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(nmi_zbuf_clear_kernel, dim3(blocks), dim3(256), 0, stream, zbuf, n);
+    hipLaunchKernelGGL(nmi_zbuf_clear_kernel, dim3((unsigned)((nz + 255) / 256 < 4096 ? (nz + 255) / 256 : 4096)), dim3(256), 0, stream, zbuf, nz);
     if (npoints > 0) {
-        dim3 grid((unsigned)((npoints + 255) / 256), (unsigned)S);
-        hipLaunchKernelGGL(nmi_splat_kernel, grid, dim3(256), 0, stream, xyz, red, npoints, mvps, zbuf, width, height, size);
+        const size_t per_view = (size_t)(width + size - 1) * (height + size - 1);
+        for (int s0 = 0; s0 < S; s0 += kMaxViewsPerLaunch) {
+            const int views = S - s0 < kMaxViewsPerLaunch ? S - s0 : kMaxViewsPerLaunch;
+            hipLaunchKernelGGL(nmi_splat_kernel, dim3((unsigned)((npoints + 255) / 256)), dim3(256), 0, stream, xyz, red, npoints,
+                               mvps + (size_t)s0 * 16, views, zbuf + (size_t)s0 * per_view, width, height, size);
+        }
     }
-    hipLaunchKernelGGL(nmi_zbuf_resolve_kernel, dim3(blocks), dim3(256), 0, stream, zbuf, out, n);
+    hipLaunchKernelGGL(nmi_zbuf_resolve_kernel, dim3((unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192)), dim3(256), 0, stream, zbuf, out,
+                       S, width, height, size);
     return hipGetLastError();
 }
 
