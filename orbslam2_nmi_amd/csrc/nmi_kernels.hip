@@ -1035,18 +1035,35 @@ __global__ __launch_bounds__(256) void nmi_splat_kernel(const float *__restrict_
     }
 }
 
+// Four horizontally adjacent output pixels per lane: the size x (size+3) anchor window is read once and the four
+// results leave as one dword.
 __global__ __launch_bounds__(256) void nmi_zbuf_resolve_kernel(const uint32_t *__restrict__ zbuf, uint8_t *__restrict__ out, int views,
                                                                int width, int height, int size)
 {
     const int wp = width + size - 1, hp = height + size - 1;
-    const size_t n = (size_t)views * width * height;
+    const int quads = (width + 3) / 4;
+    const size_t n = (size_t)views * height * quads;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int px = (int)(i % width), py = (int)((i / width) % height), s = (int)(i / ((size_t)width * height));
+        const int q = (int)(i % quads), py = (int)((i / quads) % height), s = (int)(i / ((size_t)quads * height));
+        const int px = q * 4;
         const uint32_t *base = zbuf + (size_t)s * wp * hp + (size_t)py * wp + px;
-        uint32_t best = 0xFFFFFFFFu;
-        for (int dy = 0; dy < size; ++dy)
-            for (int dx = 0; dx < size; ++dx) best = min(best, base[(size_t)dy * wp + dx]);
-        out[i] = (uint8_t)(best & 0xFFu);  // untouched pixels keep the clear colour 255
+        uint32_t best[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        for (int dy = 0; dy < size; ++dy) {
+            const uint32_t *row = base + (size_t)dy * wp;
+            for (int dx = 0; dx < size + 3; ++dx) {
+                if (px + dx >= wp) break;
+                const uint32_t v = row[dx];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (dx >= k && dx - k < size) best[k] = min(best[k], v);
+            }
+        }
+        uint8_t *dst = out + ((size_t)s * height + py) * width + px;
+        if (px + 3 < width && (width & 3) == 0) {
+            *reinterpret_cast<uint32_t *>(dst) = (best[0] & 0xFFu) | ((best[1] & 0xFFu) << 8) | ((best[2] & 0xFFu) << 16) | (best[3] << 24);
+        } else {
+            for (int k = 0; k < 4 && px + k < width; ++k) dst[k] = (uint8_t)(best[k] & 0xFFu);  // untouched pixels keep 255
+        }
     }
 }
 
@@ -1066,8 +1083,10 @@ hipError_t launch_render_points(const float *xyz, const float *red, long long np
                                mvps + (size_t)s0 * 16, views, zbuf + (size_t)s0 * per_view, width, height, size);
         }
     }
-    hipLaunchKernelGGL(nmi_zbuf_resolve_kernel, dim3((unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192)), dim3(256), 0, stream, zbuf, out,
-                       S, width, height, size);
+    const size_t nq = (size_t)S * height * ((width + 3) / 4);
+    hipLaunchKernelGGL(nmi_zbuf_resolve_kernel, dim3((unsigned)((nq + 255) / 256 < 8192 ? (nq + 255) / 256 : 8192)), dim3(256), 0, stream, zbuf,
+                       out, S, width, height, size);
+    (void)n;
     return hipGetLastError();
 }
 
