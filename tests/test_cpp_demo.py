@@ -19,7 +19,8 @@ def test_demo_builds():
 
 @pytest.mark.gpu
 def test_demo_recovers_planted_offset():
-    assert os.access(EXE, os.X_OK), "examples/relocalize_demo must be built (python __graft_entry__.py)"
+    if not os.access(EXE, os.X_OK):  # normally prebuilt by __graft_entry__.build(); hipcc exists on the GPU box too
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
