@@ -222,6 +222,7 @@ int main()
     printf("shim NMIWithCuda_noMask(render 0, warp 2) = %.7f, grid rating = %.7f\n", nmi_shim, table[2]);
     ok = ok && nmi_shim == table[2];
     (void)hipFree(d_rot);
+    CUDAF::Shutdown();
     (void)hipFree(d.d_frame);
     (void)hipFree(d.d_renders);
     (void)hipFree(d.d_warps);

@@ -173,7 +173,7 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     a.table = ctx->table;
     a.scratch = ctx->d_scratch;
     a.order = nullptr;
-    if (ctx->xcd_tiling && (int64_t)S_local * Wn > 0) {
+    if (ctx->xcd_tiling && (int64_t)S_local * Wn > 0 && (int64_t)S_local * Wn <= (1ll << 24)) {  // 4 B per candidate
         const int orc = ensure_order(ctx, S_local, Wn);
         if (orc != NMI_OK) return orc;
         a.order = ctx->d_order;
@@ -219,7 +219,7 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
         ctx->scratch_workgroups = alloc;
         a.scratch = ctx->d_scratch;
     a.order = nullptr;
-    if (ctx->xcd_tiling && (int64_t)S_local * Wn > 0) {
+    if (ctx->xcd_tiling && (int64_t)S_local * Wn > 0 && (int64_t)S_local * Wn <= (1ll << 24)) {  // 4 B per candidate
         const int orc = ensure_order(ctx, S_local, Wn);
         if (orc != NMI_OK) return orc;
         a.order = ctx->d_order;

@@ -36,10 +36,8 @@ namespace detail {
 struct State {
     std::map<unsigned int, const uint8_t *> renders;          // GL texture name -> linear device copy
     std::map<std::pair<int, int>, nmi_ctx *> contexts;        // one persistent workspace per frame size
-    ~State()
-    {
-        for (auto &kv : contexts) nmi_destroy(kv.second);
-    }
+    // No destructor on purpose: this object dies during static destruction, possibly after the HIP runtime has shut
+    // down; call CUDAF::Shutdown() to release the workspaces earlier (the reference frees per call, kernel.cu:103-113).
 };
 inline State &state()
 {
@@ -74,6 +72,14 @@ inline nmi_ctx *context(int width, int height)
 // exactly as glReadPixels / the mapped cudaArray would give them).
 inline void RegisterRenderBuffer(unsigned int syntGL, const unsigned char *d_render) { detail::state().renders[syntGL] = d_render; }
 inline void UnregisterRenderBuffer(unsigned int syntGL) { detail::state().renders.erase(syntGL); }
+
+// Releases every workspace the shim created (optional; safe to call at any point where no search is running).
+inline void Shutdown()
+{
+    for (auto &kv : detail::state().contexts) nmi_destroy(kv.second);
+    detail::state().contexts.clear();
+    detail::state().renders.clear();
+}
 
 // Identical signature to kernel.cuh:37.
 inline void NMIWithCuda_noMask(cv::cuda::PtrStep<unsigned char> *d_Warped, int /*NMI_mode*/, int /*MatchingMode*/, int width,
