@@ -247,6 +247,13 @@ def main():
     torch.cuda.synchronize()
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
+    if world > 1:
+        # The search kernel holds one workgroup per CU for its whole run (LDS-limited).  Leave one CU per XCD to the
+        # collective's kernel so that the 8-byte all-reduce of step i can run beside step i+1 instead of queueing for a
+        # CU: 729 candidates are 3 rounds on 248 workgroups exactly as on 256, so this costs the search nothing.
+        cus = ctx.info()["compute_units"]
+        if cus >= 64:
+            ctx.set_option(ctx.OPT_WORKGROUPS, cus - 8)
     key = torch.zeros(1, dtype=torch.int64, device="cuda")
 
     from orbslam2_nmi_amd import sharding
