@@ -189,6 +189,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--blocking", action="store_true", help="latency mode: one blocking search per step")
+    ap.add_argument("--streams", type=int, default=2, help="searches kept in flight in throughput mode (contexts / streams)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--all-on-device0", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo; numbers are meaningless)")
@@ -241,19 +242,28 @@ def main():
     w_c, s_c = divmod(wl["planted"], S_PER_RANK)
     planted_global = w_c * S_total + s_c
 
-    ctx = nmi.NmiContext(WIDTH, HEIGHT, bins=BINS, max_candidates=S_PER_RANK * WN)
-    # one non-default stream carries everything: the HIP kernel, the collective's dependency, the read-backs
-    stream = torch.cuda.Stream()
+    # Throughput mode keeps --streams searches in flight, each on its own context and non-default stream: a 729-candidate
+    # search is 2.85 rounds of the chip, so the workgroups of the next search fill the CUs that the last round (and the
+    # launch / completion latency) of the previous one leaves idle.  Every stream carries its kernels, the collective's
+    # dependency and the read-backs.  --blocking uses one stream.
+    n_streams = 1 if args.blocking else max(1, args.streams)
     torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(n_streams)]
+    ctxs = []
+    for st_ in streams:
+        c = nmi.NmiContext(WIDTH, HEIGHT, bins=BINS, max_candidates=S_PER_RANK * WN)
+        c.set_stream(st_.cuda_stream)
+        ctxs.append(c)
+    ctx, stream = ctxs[0], streams[0]
     torch.cuda.set_stream(stream)
-    ctx.set_stream(stream.cuda_stream)
     if world > 1:
         # The search kernel holds one workgroup per CU for its whole run (LDS-limited).  Leave one CU per XCD to the
         # collective's kernel so that the 8-byte all-reduce of step i can run beside step i+1 instead of queueing for a
         # CU: 729 candidates are 3 rounds on 248 workgroups exactly as on 256, so this costs the search nothing.
         cus = ctx.info()["compute_units"]
         if cus >= 64:
-            ctx.set_option(ctx.OPT_WORKGROUPS, cus - 8)
+            for c in ctxs:
+                c.set_option(c.OPT_WORKGROUPS, cus - 8)
     key = torch.zeros(1, dtype=torch.int64, device="cuda")
 
     from orbslam2_nmi_amd import sharding
@@ -279,11 +289,16 @@ def main():
         works = []
         for i in range(n):
             slot = keys[i:i + 1]
-            ctx.search_grid_shard(rs, s_offset, S_total, ws, key_out=slot, blocking=False)
+            k = i % n_streams
+            torch.cuda.set_stream(streams[k])
+            ctxs[k].search_grid_shard(rs, s_offset, S_total, ws, key_out=slot, blocking=False)
             if dist is not None:
                 works.append(dist.all_reduce(slot, op=dist.ReduceOp.MAX, async_op=True))  # 8 bytes over RCCL/xGMI
+        torch.cuda.set_stream(streams[0])
         for wk in works:
             wk.wait()
+        for st_ in streams[1:]:
+            streams[0].wait_stream(st_)
         got = keys[:n].cpu().tolist()  # one read-back of all winners; synchronises the stream
         bad = [g for g in got if nmi.key_unpack(g)[0] != planted_global]
         if bad:
@@ -343,6 +358,7 @@ def main():
             "step_mode": "blocking call per step" if args.blocking else
                          "steps enqueued back to back; every step's winner read back and checked inside the timed region",
             "blocking_call_ms": blocking_call_ms,
+            "streams": n_streams,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -361,7 +377,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_budget, args.cpu_threads)
         print(json.dumps(out))
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
