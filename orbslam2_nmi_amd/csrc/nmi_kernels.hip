@@ -192,6 +192,36 @@ __device__ __forceinline__ void add_chunk(Lds &lds, int par, const uint4 &rv, co
             return;
         }
     }
+    if (HIST == 2 && BG && !SHIFTED) {
+        // The hot case, written so that each pixel costs 5 VALU + 1 DS: byte address = d1 * 512 + (d2 & 127) * 4 from one
+        // byte-select shift of the render dword and one shift + and-or of the frame dword; increment 1 + 0xFFFF * bit7(d2).
+        // hipcc re-derives 7 instructions from the plain C expressions (mask + compare + select for the increment, a
+        // separate mask for the render byte), so the five are spelled out: SDWA byte-select shift, shift, and-or, bit-field
+        // extract, 24-bit multiply-add.
+        char *const base = reinterpret_cast<char *>(lds.joint);
+        const uint32_t nine = 9, mask_1fc = 0x1FCu, k_ffff = 0xFFFFu;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t a1, a2, addr, hi, val;
+                if (j == 0)
+                    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(a1) : "v"(nine), "v"(r[q]));
+                else if (j == 1)
+                    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(a1) : "v"(nine), "v"(r[q]));
+                else if (j == 2)
+                    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(a1) : "v"(nine), "v"(r[q]));
+                else
+                    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(a1) : "v"(nine), "v"(r[q]));
+                a2 = j == 0 ? (w[q] << 2) : (w[q] >> (8 * j - 2));
+                asm("v_and_or_b32 %0, %1, %3, %2" : "=v"(addr) : "v"(a2), "v"(a1), "s"(mask_1fc));  // VOP3: no literals on gfx9
+                hi = __builtin_amdgcn_ubfe(w[q], 8 * j + 7, 1);
+                asm("v_mad_u32_u24 %0, %1, %2, 1" : "=v"(val) : "v"(hi), "s"(k_ffff));
+                (void)__hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(base + addr), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        return;
+    }
     uint32_t old[16];
     uint32_t any = 0;  // max over pixels of (old | ~field): 0xFFFFFFFF iff some counter wrapped
 #pragma unroll
