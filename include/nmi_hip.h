@@ -163,6 +163,20 @@ int nmi_render_points(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int6
                       float point_size, uint8_t *d_render_stack);
 
 /*
+ * One whole search level on the device as a captured HIP graph: S renders of the cloud (nmi_render_points), Wn warps of the
+ * frame (nmi_warp_stack), the S x Wn search (nmi_search_grid) and the winner's copy to the host replay with a single
+ * hipGraphLaunch.  Create once per (cloud, frame, S, Wn); nmi_level_run takes this level's S view matrices
+ * (nmi_render_mvp, float[S][16]) and Wn forward homographies (nmi_warp_homographies, double[Wn][9]) and blocks for the
+ * winner.  Same results as the three calls made one after the other.  The device pointers given at creation must stay
+ * valid and unchanged in place (their contents may change between runs).
+ */
+typedef struct nmi_level nmi_level;
+int nmi_level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int64_t n_points, const uint8_t *d_frame, int32_t S,
+                     int32_t Wn, float point_size, nmi_level **out);
+int nmi_level_run(nmi_level *lv, const float *h_mvps, const double *h_forward, int64_t *h_best_index, float *h_best_score);
+int nmi_level_destroy(nmi_level *lv);
+
+/*
  * Streaming form (BASELINE.json config 5): keyframes / search levels whose render stacks arrive from host memory.
  * A stream owns `depth` device slots; nmi_stream_submit enqueues, without blocking,
  *   copy stream    : hipMemcpyAsync of the pinned host render stack [S][H][W] (and the frame [H][W], if given) into a slot

@@ -23,7 +23,7 @@ ERR_NOT_READY = -4
 # Every symbol include/nmi_hip.h declares; tests check that the library exports all of them.
 EXPORTED_SYMBOLS = (
     "nmi_params_default", "nmi_create", "nmi_destroy", "nmi_set_stream", "nmi_synchronize", "nmi_eval_pair", "nmi_eval_pair_debug",
-    "nmi_search_grid", "nmi_search_grid_shard", "nmi_warp_homographies", "nmi_warp_stack", "nmi_render_mvp", "nmi_render_points", "nmi_stream_create", "nmi_stream_destroy",
+    "nmi_search_grid", "nmi_search_grid_shard", "nmi_warp_homographies", "nmi_warp_stack", "nmi_render_mvp", "nmi_render_points", "nmi_level_create", "nmi_level_run", "nmi_level_destroy", "nmi_stream_create", "nmi_stream_destroy",
     "nmi_stream_submit", "nmi_stream_wait", "nmi_key_pack", "nmi_key_unpack", "nmi_search_grid_rccl",
     "nmi_rccl_unique_id", "nmi_rccl_comm_init", "nmi_rccl_comm_destroy", "nmi_set_profiling", "nmi_last_kernel_ms",
     "nmi_set_option", "nmi_abi_version", "nmi_error_string", "nmi_last_error_detail", "nmi_get_info",
@@ -82,6 +82,9 @@ def load_library(build_if_missing=False):
     lib.nmi_warp_stack.argtypes = [vp, vp, C.POINTER(C.c_double), i32, vp]
     lib.nmi_render_mvp.argtypes = [C.POINTER(RenderParams), f32p, f32p, f32p, f32p, f32p]
     lib.nmi_render_points.argtypes = [vp, vp, vp, C.c_int64, f32p, i32, C.c_float, vp]
+    lib.nmi_level_create.argtypes = [vp, vp, vp, C.c_int64, vp, i32, i32, C.c_float, C.POINTER(vp)]
+    lib.nmi_level_run.argtypes = [vp, f32p, C.POINTER(C.c_double), i64p, f32p]
+    lib.nmi_level_destroy.argtypes = [vp]
     lib.nmi_stream_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
     lib.nmi_stream_destroy.argtypes = [vp]
     lib.nmi_stream_submit.argtypes = [vp, vp, i32, vp, C.POINTER(C.c_double), i32, i64p]
@@ -369,6 +372,40 @@ class NmiContext:
                                                    Wn, self._ratings_ptr(ratings, Wn, S), comm, C.byref(idx),
                                                    C.byref(sc)), "nmi_search_grid_rccl")
         return int(idx.value), np.float32(sc.value)
+
+
+class NmiLevel:
+    """nmi_level wrapper: cloud + frame -> renders, warps, search, winner as one captured HIP graph."""
+
+    def __init__(self, ctx, xyz, red, frame, S, Wn, point_size):
+        self.ctx, self._lib = ctx, ctx._lib
+        self._keep = (xyz, red, frame)  # the graph holds their device addresses
+        self.S, self.Wn = int(S), int(Wn)
+        self._h = C.c_void_p()
+        ctx._order_after_torch()
+        ctx._check(self._lib.nmi_level_create(ctx._h, xyz.data_ptr(), red.data_ptr(), xyz.shape[0], frame.data_ptr(), self.S,
+                                              self.Wn, float(point_size), C.byref(self._h)), "nmi_level_create")
+
+    def run(self, mvps, homographies):
+        m = np.ascontiguousarray(mvps, np.float32).reshape(-1)
+        h = np.ascontiguousarray(homographies, np.float64).reshape(-1)
+        assert m.size == self.S * 16 and h.size == self.Wn * 9
+        idx, sc = C.c_int64(0), C.c_float(0)
+        self.ctx._check(self._lib.nmi_level_run(self._h, m.ctypes.data_as(C.POINTER(C.c_float)),
+                                                h.ctypes.data_as(C.POINTER(C.c_double)), C.byref(idx), C.byref(sc)),
+                        "nmi_level_run")
+        return int(idx.value), np.float32(sc.value)
+
+    def close(self):
+        if self._h and self._h.value:
+            self._lib.nmi_level_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 class NmiStream:

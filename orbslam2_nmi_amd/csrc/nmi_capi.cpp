@@ -119,6 +119,16 @@ int ensure_ratings(nmi_ctx *ctx, int64_t n)
 
 // Visiting order of the candidates of an S x Wn grid: tiles of kTileW warps x kTileS renders (32 candidates = the
 // 32 workgroups one XCD runs at a time), tile after tile; within a tile render-fastest.  Cached per grid shape.
+void build_order(int S, int Wn, int *order)
+{
+    const int tile_s = S >= 8 ? 8 : (S >= 4 ? 4 : (S >= 2 ? 2 : 1)), tile_w = 32 / tile_s;
+    int64_t o = 0;
+    for (int w0 = 0; w0 < Wn; w0 += tile_w)
+        for (int s0 = 0; s0 < S; s0 += tile_s)
+            for (int w = w0; w < w0 + tile_w && w < Wn; ++w)
+                for (int s = s0; s < s0 + tile_s && s < S; ++s) order[o++] = w * S + s;
+}
+
 int ensure_order(nmi_ctx *ctx, int S, int Wn)
 {
     if (!ctx->xcd_tiling) return NMI_OK;
@@ -136,12 +146,7 @@ int ensure_order(nmi_ctx *ctx, int S, int Wn)
     } else {
         NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the staging copy may still feed an earlier upload
     }
-    const int tile_s = S >= 8 ? 8 : (S >= 4 ? 4 : (S >= 2 ? 2 : 1)), tile_w = 32 / tile_s;
-    int64_t o = 0;
-    for (int w0 = 0; w0 < Wn; w0 += tile_w)
-        for (int s0 = 0; s0 < S; s0 += tile_s)
-            for (int w = w0; w < w0 + tile_w && w < Wn; ++w)
-                for (int s = s0; s < s0 + tile_s && s < S; ++s) ctx->h_order[o++] = w * S + s;
+    build_order(S, Wn, ctx->h_order);
     NMI_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order, ctx->h_order, (size_t)total * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     ctx->order_S = S;
     ctx->order_Wn = Wn;
@@ -218,12 +223,6 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
         NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_scratch, nmi::grid_kernel_scratch_bytes(alloc)));
         ctx->scratch_workgroups = alloc;
         a.scratch = ctx->d_scratch;
-    a.order = nullptr;
-    if (ctx->xcd_tiling && (int64_t)S_local * Wn > 0 && (int64_t)S_local * Wn <= (1ll << 24)) {  // 4 B per candidate
-        const int orc = ensure_order(ctx, S_local, Wn);
-        if (orc != NMI_OK) return orc;
-        a.order = ctx->d_order;
-    }
     }
     if (ctx->profiling) NMI_HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     NMI_HIP_TRY(ctx, nmi::launch_grid(a, workgroups, p.use_bg != 0, ctx->stream));
@@ -650,6 +649,164 @@ int nmi_render_points(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int6
     NMI_HIP_TRY(ctx, nmi::launch_render_points(d_xyz, d_red, n_points, ring.d[slot], S, ctx->d_zbuf, d_render_stack, ctx->params.width,
                                                ctx->params.height, size, ctx->stream));
     return NMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// One search level as a captured HIP graph: cloud -> S renders, frame -> Wn warps, grid search, winner to the host.
+// Seven dependent operations (two parameter uploads, clear, splat, resolve, warp, key reset + search, winner copy)
+// replay with one hipGraphLaunch; only the pinned parameter buffers change between replays.
+// ---------------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+struct nmi_level {
+    nmi_ctx *ctx = nullptr;
+    int S = 0, Wn = 0, size = 1;
+    uint8_t *d_renders = nullptr, *d_warps = nullptr;
+    uint32_t *d_zbuf = nullptr;
+    float *d_mvps = nullptr, *h_mvps = nullptr, *d_coeffs = nullptr, *h_coeffs = nullptr;
+    int *d_order = nullptr;
+    unsigned long long *d_key = nullptr, *h_key = nullptr;
+    unsigned int *d_done = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+extern "C" {
+
+int nmi_level_destroy(nmi_level *lv)
+{
+    if (!lv) return NMI_OK;
+    DeviceGuard guard(lv->ctx->device);
+    (void)hipStreamSynchronize(lv->ctx->stream);
+    if (lv->exec) (void)hipGraphExecDestroy(lv->exec);
+    if (lv->graph) (void)hipGraphDestroy(lv->graph);
+    void *dev[] = {lv->d_renders, lv->d_warps, lv->d_zbuf, lv->d_mvps, lv->d_coeffs, lv->d_order, lv->d_key, lv->d_done};
+    for (void *q : dev)
+        if (q) (void)hipFree(q);
+    void *host[] = {lv->h_mvps, lv->h_coeffs, lv->h_key};
+    for (void *q : host)
+        if (q) (void)hipHostFree(q);
+    delete lv;
+    return NMI_OK;
+}
+
+int nmi_level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int64_t n_points, const uint8_t *d_frame, int32_t S,
+                     int32_t Wn, float point_size, nmi_level **out)
+{
+    if (!ctx || !out || !d_frame || S <= 0 || Wn <= 0 || n_points < 0 || (n_points > 0 && (!d_xyz || !d_red)))
+        return NMI_ERR_INVALID_ARGUMENT;
+    if (!ctx->params.use_bg) return NMI_ERR_UNSUPPORTED;
+    *out = nullptr;
+    ctx->detail.clear();
+    DeviceGuard guard(ctx->device);
+    nmi_level *lv = new (std::nothrow) nmi_level;
+    if (!lv) return NMI_ERR_INVALID_ARGUMENT;
+    lv->ctx = ctx;
+    lv->S = S;
+    lv->Wn = Wn;
+    int size = (int)floorf(point_size + 0.5f);
+    lv->size = size < 1 ? 1 : (size > 64 ? 64 : size);
+    const nmi_params &p = ctx->params;
+    const size_t npix = (size_t)ctx->npix;
+    const int64_t total = (int64_t)S * Wn;
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t r) {
+        if (e == hipSuccess) e = r;
+        return r == hipSuccess;
+    };
+    ok(hipMalloc((void **)&lv->d_renders, npix * S));
+    ok(hipMalloc((void **)&lv->d_warps, npix * Wn));
+    ok(hipMalloc((void **)&lv->d_zbuf, nmi::render_zbuf_words(S, p.width, p.height, lv->size) * sizeof(uint32_t)));
+    ok(hipMalloc((void **)&lv->d_mvps, (size_t)S * 16 * sizeof(float)));
+    ok(hipMalloc((void **)&lv->d_coeffs, (size_t)Wn * 9 * sizeof(float)));
+    ok(hipMalloc((void **)&lv->d_order, (size_t)total * sizeof(int)));
+    ok(hipMalloc((void **)&lv->d_key, sizeof(unsigned long long)));
+    ok(hipMalloc((void **)&lv->d_done, sizeof(unsigned int)));
+    ok(hipHostMalloc((void **)&lv->h_mvps, (size_t)S * 16 * sizeof(float), hipHostMallocDefault));
+    ok(hipHostMalloc((void **)&lv->h_coeffs, (size_t)Wn * 9 * sizeof(float), hipHostMallocDefault));
+    ok(hipHostMalloc((void **)&lv->h_key, sizeof(unsigned long long), hipHostMallocDefault));
+    int *order = e == hipSuccess ? new (std::nothrow) int[(size_t)total] : nullptr;
+    if (e != hipSuccess || !order) {
+        const int rc = e != hipSuccess ? hip_fail(ctx, e, "nmi_level_create") : NMI_ERR_INVALID_ARGUMENT;
+        nmi_level_destroy(lv);
+        return rc;
+    }
+    build_order(S, Wn, order);
+    ok(hipMemcpy(lv->d_order, order, (size_t)total * sizeof(int), hipMemcpyHostToDevice));
+    delete[] order;
+    ok(hipMemset(lv->d_done, 0, sizeof(unsigned int)));
+    memset(lv->h_mvps, 0, (size_t)S * 16 * sizeof(float));
+    memset(lv->h_coeffs, 0, (size_t)Wn * 9 * sizeof(float));
+    ok(hipDeviceSynchronize());
+
+    nmi::GridArgs a{};
+    a.render_stack = lv->d_renders;
+    a.warp_stack = lv->d_warps;
+    a.S_local = S;
+    a.Wn = Wn;
+    a.s_offset = 0;
+    a.S_total = S;
+    a.width = p.width;
+    a.height = p.height;
+    a.npix = ctx->npix;
+    a.vec_ok = (p.width % 16 == 0) && (((uintptr_t)lv->d_renders | (uintptr_t)lv->d_warps) % 16 == 0);
+    a.chunks_per_row = a.vec_ok ? p.width / 16 : 1;
+    a.cpr_magic = a.chunks_per_row > 1 ? (uint32_t)((0x100000000ull + a.chunks_per_row - 1) / a.chunks_per_row) : 0u;
+    a.shift = ctx->shift;
+    a.mode = p.mode;
+    a.flip = p.render_bottom_up ? 1 : 0;
+    a.table = ctx->table;
+    a.order = lv->d_order;
+    a.key = lv->d_key;        // reset by a memset node before every replay (the ping-pong of plain launches needs
+    a.reset_key = nullptr;    // alternating arguments, which a replayed graph does not have)
+    a.done = lv->d_done;
+    a.hist_variant = 3;
+    a.phase_mask = 3;
+    const int cap = ctx->workgroups > 0 ? ctx->workgroups : ctx->compute_units;
+    const int workgroups = (int)(total < cap ? total : cap);
+
+    hipStream_t st = ctx->stream;
+    if (ok(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal))) {
+        ok(hipMemcpyAsync(lv->d_mvps, lv->h_mvps, (size_t)S * 16 * sizeof(float), hipMemcpyHostToDevice, st));
+        ok(nmi::launch_render_points(d_xyz, d_red, n_points, lv->d_mvps, S, lv->d_zbuf, lv->d_renders, p.width, p.height, lv->size, st));
+        ok(hipMemcpyAsync(lv->d_coeffs, lv->h_coeffs, (size_t)Wn * 9 * sizeof(float), hipMemcpyHostToDevice, st));
+        ok(nmi::launch_warp(d_frame, lv->d_coeffs, lv->d_warps, p.width, p.height, Wn, st));
+        ok(hipMemsetAsync(lv->d_key, 0, sizeof(unsigned long long), st));
+        ok(nmi::launch_grid(a, workgroups, true, st));
+        ok(hipMemcpyAsync(lv->h_key, lv->d_key, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        hipError_t ec = hipStreamEndCapture(st, &lv->graph);
+        ok(ec);
+    }
+    if (e == hipSuccess) ok(hipGraphInstantiate(&lv->exec, lv->graph, nullptr, nullptr, 0));
+    if (e != hipSuccess) {
+        const int rc = hip_fail(ctx, e, "nmi_level_create (graph capture)");
+        nmi_level_destroy(lv);
+        return rc;
+    }
+    *out = lv;
+    return NMI_OK;
+}
+
+int nmi_level_run(nmi_level *lv, const float *h_mvps, const double *h_forward, int64_t *h_best_index, float *h_best_score)
+{
+    if (!lv || !h_mvps || !h_forward) return NMI_ERR_INVALID_ARGUMENT;
+    nmi_ctx *ctx = lv->ctx;
+    ctx->detail.clear();
+    DeviceGuard guard(ctx->device);
+    // the previous replay has completed (this call is blocking), so the pinned parameter buffers are free to rewrite
+    memcpy(lv->h_mvps, h_mvps, (size_t)lv->S * 16 * sizeof(float));
+    for (int w = 0; w < lv->Wn; ++w) {
+        const double *m = h_forward + (size_t)w * 9;
+        const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+        if (det == 0.0) return NMI_ERR_INVALID_ARGUMENT;
+        const double inv[9] = {(m[4] * m[8] - m[5] * m[7]) / det, (m[2] * m[7] - m[1] * m[8]) / det, (m[1] * m[5] - m[2] * m[4]) / det,
+                               (m[5] * m[6] - m[3] * m[8]) / det, (m[0] * m[8] - m[2] * m[6]) / det, (m[2] * m[3] - m[0] * m[5]) / det,
+                               (m[3] * m[7] - m[4] * m[6]) / det, (m[1] * m[6] - m[0] * m[7]) / det, (m[0] * m[4] - m[1] * m[3]) / det};
+        for (int k = 0; k < 9; ++k) lv->h_coeffs[w * 9 + k] = (float)inv[k];
+    }
+    NMI_HIP_TRY(ctx, hipGraphLaunch(lv->exec, ctx->stream));
+    NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return nmi_key_unpack(*lv->h_key, h_best_index, h_best_score);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -119,3 +119,32 @@ def test_gpu_cloud_to_winner_end_to_end():
     assert cells[idx] == truth_cell and best > 0.3
     tab = t.cpu().numpy().reshape(-1)
     assert best > 1.5 * np.sort(tab)[-2]
+
+
+@pytest.mark.gpu
+def test_gpu_level_graph_equals_separate_calls():
+    """nmi_level_* (renders + warps + search + winner as one captured HIP graph) gives exactly what the three calls give,
+    replay after replay with changing matrices."""
+    torch = pytest.importorskip("torch")
+    import orbslam2_nmi_amd as nmi
+    from orbslam2_nmi_amd import hostapi as H
+    w, h = 160, 120
+    xyz, red, rp = plane_cloud(w, h, density=2.0)
+    Twc = np.eye(4, dtype=np.float32)
+    Twc[:3, 1] = [0, -1, 0]
+    pos, look, up = Twc[:3, 3], Twc[:3, 3] + Twc[:3, 2], Twc[:3, 1]
+    cells = [(sx, sy, sz) for sz in range(2) for sy in range(2) for sx in range(2)]
+    K = sy.intrinsics(w, h)
+    with nmi.NmiContext(w, h) as ctx:
+        dx, dr = torch.from_numpy(xyz).cuda(), torch.from_numpy(red).cuda()
+        frame = torch.flip(ctx.render_points(dx, torch.sqrt(dr), capi.render_mvp(rp, pos, look, up, (0.05, 0, 0))[None], 3.0)[0],
+                           dims=[0]).contiguous()
+        with nmi.NmiLevel(ctx, dx, dr, frame, 8, 12, 3.0) as lv:
+            for lvl in range(4):
+                g = H.SearchKernel.make([2, 2, 2, 3, 2, 2], [s / 2 ** lvl for s in (0.2, 0.2, 0.5, 0.02, 0.02, 0.05)])
+                mvps = np.stack([capi.render_mvp(rp, pos, look, up, H.calculate_translation(Twc, g, *c)) for c in cells])
+                Ms = capi.warp_homographies(K, (3, 2, 2), tuple(g.step[3:6]))
+                got = lv.run(mvps, Ms)
+                rs = ctx.render_points(dx, dr, mvps, 3.0)
+                ws = ctx.warp_stack(frame, Ms)
+                assert got == ctx.search_grid(rs, ws), lvl
