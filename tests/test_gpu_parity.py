@@ -423,3 +423,28 @@ def test_randomised_shapes_and_switches(nmi):
             f = r.copy()
         check_pair(nmi, oc, r, f, bins=int(rng.choice([256, 64])), mode=int(rng.integers(0, 2)),
                    bg=bool(rng.integers(0, 2)), bu=bool(rng.integers(0, 2)))
+
+
+def test_empty_grids_and_maximum_frame(nmi):
+    """Edge sizes: grids with no candidates give "no winner" (index -1, score 0) without touching the inputs; the largest
+    frame the library accepts (4096x4096 = 2^24 pixels, counts still exact in fp32) matches the oracle, wraps included."""
+    from oracle import binding as oc
+    with nmi.NmiContext(64, 48) as ctx:
+        rs0 = torch.zeros((0, 48, 64), dtype=torch.uint8, device="cuda")
+        ws = torch.zeros((2, 48, 64), dtype=torch.uint8, device="cuda")
+        assert ctx.search_grid(rs0, ws) == (-1, np.float32(0))
+        assert ctx.search_grid(ws, rs0) == (-1, np.float32(0))
+        assert ctx.search_grid_shard(rs0, 0, 0, ws) == 0
+        assert ctx.search_grid(ws[:1], ws[:1])[0] == 0          # and the context still works afterwards
+    rng = np.random.default_rng(99)
+    n = 4096
+    r = rng.integers(0, 256, (n, n), dtype=np.uint8)
+    f = np.clip(r.astype(np.int16) + rng.integers(-3, 4, (n, n), dtype=np.int16), 0, 255).astype(np.uint8)
+    r[: n // 2, : n // 2] = 255                                   # 4.2 M pixels in one bin: 64 wraps of a 16-bit counter
+    f[: n // 2, : n // 2] = 0
+    with nmi.NmiContext(n, n, render_bottom_up=False) as ctx:
+        s, j, h1, h2, sums = ctx.eval_pair_debug(dev(r), dev(f))
+    jo, h1o, h2o = oc.joint_hist(r, f, 0, True, False)
+    so, sums_o = oc.score_from_hist(jo, h1o, h2o, n * n)
+    assert (j == jo).all() and (h1 == h1o).all() and (h2 == h2o).all()
+    assert j[255, 0] >= (n // 2) ** 2 and abs(float(s) - float(so)) <= SCORE_TOL
