@@ -7,11 +7,12 @@
 //   Thirdparty/CUDA_Functions/NMI.cu:342-362  SUC / ENMI score with the all-zero guard
 //   Thirdparty/Localization/helperFunctions.cpp:50-103  arg-max (strict '>' from 0, lowest index on ties)
 // How it is computed is new: one 1024-lane workgroup per pose candidate owns the whole
-// 256x256 joint histogram in LDS as packed 16-bit counters (128 KiB of the CU's 160 KiB), with exact
-// wrap bookkeeping so counts above 65535 stay exact; the entropy terms come from a per-context table
-// indexed by count; the trees are evaluated in registers / cross-lane in the reference's order; the
+// 256x256 joint histogram in LDS as packed 16-bit counters (128 KiB of the CU's 160 KiB); counts above 65535
+// are caught by a pixel-count test and redone with exact wrap bookkeeping; the entropy terms come from a
+// per-context table indexed by count; the trees are evaluated in registers / DPP in the reference's order; the
 // score, the rating-table store and the arg-max (one 64-bit atomicMax per candidate) are fused into the
-// same launch.  Histogramming is integer scatter work: no MFMA.
+// same launch.  Also here: the warp-stack and point-cloud render-stack producers.
+// Histogramming is integer scatter work: no MFMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -31,10 +32,9 @@ constexpr int kLdsTable = 4096;            // per-count entropy terms kept in LD
 
 // LDS word of joint bin (d1 = render intensity, d2 = warped-frame intensity):
 //   word = d1 * 128 + (d2 & 127), low half for d2 < 128, high half for d2 >= 128.
-// Lane l of a wavefront that reads words d1*128 + l and d1*128 + 64 + l therefore holds bins
-// d2 = l, l+64, l+128, l+192 of row d1 -- exactly the operands of the first two tree steps
-// (a[t] += a[t+128], a[t] += a[t+64]; NMI.cu:276-284), so those steps need no cross-lane traffic.
-// The LDS bank of a bin is (d2 & 31): neighbouring render intensities do not collide.
+// Each word thus holds the pair (d2, d2 + 128) -- the two operands of the first tree step a[t] += a[t+128]
+// (NMI.cu:276-284) -- and a lane that owns the words i, i+16, ..., i+112 of a row owns all operands of the steps
+// n = 128, 64, 32, 16 (decode_phase).  The LDS bank of a bin is (d2 & 31): the render intensity does not enter it.
 
 struct Lds {
     uint32_t joint[kWords];    // 128 KiB
@@ -137,7 +137,7 @@ __device__ __forceinline__ void add_pixel(Lds &lds, int par, uint32_t d1, uint32
 
 // 16 pixels of one lane.  HIST selects how wraps of the 16-bit counters are handled:
 //   0  returning atomic + test per pixel (serialises on the LDS round trip; kept as the ablation baseline)
-//   1  16 returning atomics in flight, one combined wrap test per 16 pixels (default; always exact)
+//   1  16 returning atomics in flight, one combined wrap test per 16 pixels, flat chunks folded (the exact path)
 //   2  non-returning atomics, no test: exact only when no bin can exceed 65535 (first try of the
 //      optimistic scheme HIST = 3, see nmi_grid_kernel)
 template <bool BG, bool SHIFTED, int HIST>
