@@ -207,6 +207,8 @@ def main():
     ap.add_argument("--blocking", action="store_true", help="latency mode: one blocking search per step")
     ap.add_argument("--streams", type=int, default=2, help="searches kept in flight in throughput mode (contexts / streams)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: run the N>1 code path (process group, async all-reduce per step) even with one rank")
     ap.add_argument("--all-on-device0", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo; numbers are meaningless)")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
@@ -236,8 +238,9 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29577")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -272,7 +275,7 @@ def main():
         ctxs.append(c)
     ctx, stream = ctxs[0], streams[0]
     torch.cuda.set_stream(stream)
-    if world > 1:
+    if dist is not None:
         # The search kernel holds one workgroup per CU for its whole run (LDS-limited).  Leave one CU per XCD to the
         # collective's kernel so that the 8-byte all-reduce of step i can run beside step i+1 instead of queueing for a
         # CU: 729 candidates are 3 rounds on 248 workgroups exactly as on 256, so this costs the search nothing.
@@ -294,7 +297,7 @@ def main():
     def run_blocking(n):
         res = None
         for _ in range(n):
-            if world == 1:
+            if dist is None:
                 res = ctx.search_grid(rs, ws)
             else:
                 res = sharding.sharded_search(ctx, rs, s_offset, S_total, ws, key, dist)
@@ -384,7 +387,7 @@ def main():
                                    "256-bin NMI (SUC), render axis sharded by rank",
                        "width": WIDTH, "height": HEIGHT, "renders_per_gpu": S_PER_RANK, "warps": WN,
                        "candidates_total": evals_per_step, "bins": BINS,
-                       "collective": "none" if world == 1 else "8-byte MAX all-reduce (RCCL)"},
+                       "collective": "none" if dist is None else "8-byte MAX all-reduce (RCCL)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_pmc_traffic(),
                          "kernel": "nmi_grid_kernel", "kernel_ms": kernel_ms,
