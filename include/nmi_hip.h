@@ -163,6 +163,25 @@ int nmi_render_points(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int6
                       float point_size, uint8_t *d_render_stack);
 
 /*
+ * Render-stack producer for textured meshes (nmi_prop_RENDER 1, the reference's default): replaces
+ * Rendering<1>::renderToTextureOnGPU (rendering.hpp:530-630, shaders/ShadingWithTexture.*) -- no OpenGL.
+ *   nmi_texture_create  takes the RGB8 image exactly as loadBMP_custom passes it to glTexImage2D (texture.cpp:31-86: row 0
+ *                       = v 0, three bytes per texel in file order; the shader weighs byte 0 with 0.299, byte 1 with 0.587,
+ *                       byte 2 with 0.114), builds the mip chain glGenerateMipmap would (2x2 box, RGB8 per level) and keeps
+ *                       per-level luma on the device.
+ *   nmi_render_mesh     d_xyz float [3*T][3] and d_uv float [3*T][2]: the expanded per-corner arrays loadOBJ produces
+ *                       (objloader.cpp:140-224); h_mvps as for nmi_render_points; output uint8 [S][H][W], bottom-up rows,
+ *                       background 255.  Back faces culled (counter-clockwise front), depth test LESS, GL_REPEAT,
+ *                       GL_LINEAR / GL_LINEAR_MIPMAP_LINEAR.  Triangles reaching behind the eye plane are dropped, not clipped.
+ * Enqueued on the context's stream.  Parity with an OpenGL driver is unpinned (kernel comment).
+ */
+typedef struct nmi_texture nmi_texture;
+int nmi_texture_create(nmi_ctx *ctx, const uint8_t *h_rgb, int32_t tex_width, int32_t tex_height, nmi_texture **out);
+int nmi_texture_destroy(nmi_texture *tex);
+int nmi_render_mesh(nmi_ctx *ctx, const float *d_xyz, const float *d_uv, int64_t n_triangles, const nmi_texture *tex,
+                    const float *h_mvps, int32_t S, uint8_t *d_render_stack);
+
+/*
  * One whole search level on the device as a captured HIP graph: S renders of the cloud (nmi_render_points), Wn warps of the
  * frame (nmi_warp_stack), the S x Wn search (nmi_search_grid) and the winner's copy to the host replay with a single
  * hipGraphLaunch.  Create once per (cloud, frame, S, Wn); nmi_level_run takes this level's S view matrices

@@ -1,0 +1,134 @@
+"""numpy (fp32) restatement of the textured-mesh render-stack producer -- TEST INFRASTRUCTURE ONLY.
+
+Restates Rendering<1>::renderToTextureOnGPU (Thirdparty/Localization/rendering.hpp:530-630), the shaders
+ShadingWithTexture.* (luma 0.299/0.587/0.114 of the texture sample) and the texture state of loadBMP_custom
+(texture.cpp:31-96: GL_REPEAT, GL_LINEAR, GL_LINEAR_MIPMAP_LINEAR, glGenerateMipmap) with the OpenGL 3.3 specification's
+rules in fp32: pixel centres at +0.5, top-left fill rule, back-face culling (front = counter-clockwise), perspective-
+correct attributes, isotropic LOD from per-pixel uv differences, 2x2-box mip levels rounded to RGB8.
+"PARITY UNPINNED": an OpenGL driver rasterises in fixed point and may approximate the LOD; nothing to compare against.
+Slow (python loop over triangles): small test meshes only.
+"""
+import numpy as np
+
+f32 = np.float32
+
+
+def mip_luma(rgb):
+    """-> list of float32 luma levels (row 0 = v 0), mip chain by 2x2 box on RGB8 with rounding, like nmi_texture_create."""
+    cur = np.ascontiguousarray(rgb, np.uint8)
+    levels = []
+    while True:
+        c = cur.astype(f32) / f32(255.0)
+        levels.append((f32(0.299) * c[..., 0] + f32(0.587) * c[..., 1]) + f32(0.114) * c[..., 2])
+        h, w = cur.shape[:2]
+        if (w == 1 and h == 1) or len(levels) == 16:
+            break
+        nw, nh = max(1, w // 2), max(1, h // 2)
+        x0 = np.minimum(2 * np.arange(nw), w - 1)
+        x1 = np.minimum(2 * np.arange(nw) + 1, w - 1)
+        y0 = np.minimum(2 * np.arange(nh), h - 1)
+        y1 = np.minimum(2 * np.arange(nh) + 1, h - 1)
+        s = (cur[np.ix_(y0, x0)].astype(np.int32) + cur[np.ix_(y0, x1)] + cur[np.ix_(y1, x0)] + cur[np.ix_(y1, x1)])
+        cur = ((s + 2) // 4).astype(np.uint8)
+    return levels
+
+
+def _bilinear(level, u, v):
+    h, w = level.shape
+    x = u * f32(w) - f32(0.5)
+    y = v * f32(h) - f32(0.5)
+    xf, yf = np.floor(x), np.floor(y)
+    fx, fy = x - xf, y - yf
+    i0 = np.mod(xf.astype(np.int64), w)
+    j0 = np.mod(yf.astype(np.int64), h)
+    i1 = np.where(i0 + 1 == w, 0, i0 + 1)
+    j1 = np.where(j0 + 1 == h, 0, j0 + 1)
+    t00, t10, t01, t11 = level[j0, i0], level[j0, i1], level[j1, i0], level[j1, i1]
+    a = t00 + (t10 - t00) * fx
+    b = t01 + (t11 - t01) * fx
+    return a + (b - a) * fy
+
+
+def render_mesh(xyz, uv, levels, mvp_colmajor, width, height):
+    """One view -> uint8 [H, W], bottom-up rows, background 255."""
+    m = np.asarray(mvp_colmajor, f32)
+    P = np.asarray(xyz, f32).reshape(-1, 3, 3)
+    T = np.asarray(uv, f32).reshape(-1, 3, 2)
+    zbuf = np.full((height, width), 0xFFFFFFFF, np.uint32)
+    tw, th = f32(levels[0].shape[1]), f32(levels[0].shape[0])
+    nlev = len(levels)
+    for tri in range(P.shape[0]):
+        x, y, z = P[tri, :, 0], P[tri, :, 1], P[tri, :, 2]
+        cx = (m[0] * x + m[4] * y) + (m[8] * z + m[12])
+        cy = (m[1] * x + m[5] * y) + (m[9] * z + m[13])
+        cz = (m[2] * x + m[6] * y) + (m[10] * z + m[14])
+        cw = (m[3] * x + m[7] * y) + (m[11] * z + m[15])
+        if not (cw > 0).all():
+            continue
+        if ((cx < -cw).all() or (cx > cw).all() or (cy < -cw).all() or (cy > cw).all() or (cz < -cw).all() or (cz > cw).all()):
+            continue
+        xw = (cx / cw * f32(0.5) + f32(0.5)) * f32(width)
+        yw = (cy / cw * f32(0.5) + f32(0.5)) * f32(height)
+        zw = cz / cw * f32(0.5) + f32(0.5)
+        iw = f32(1.0) / cw
+        area = (xw[1] - xw[0]) * (yw[2] - yw[0]) - (xw[2] - xw[0]) * (yw[1] - yw[0])
+        if not area > 0:
+            continue
+        x_lo = max(0, int(np.ceil(xw.min() - f32(0.5))))
+        x_hi = min(width - 1, int(np.floor(xw.max() - f32(0.5))))
+        y_lo = max(0, int(np.ceil(yw.min() - f32(0.5))))
+        y_hi = min(height - 1, int(np.floor(yw.max() - f32(0.5))))
+        if x_lo > x_hi or y_lo > y_hi:
+            continue
+        inv_area = f32(1.0) / area
+        ex = np.array([xw[(k + 2) % 3] - xw[(k + 1) % 3] for k in range(3)], f32)
+        ey = np.array([yw[(k + 2) % 3] - yw[(k + 1) % 3] for k in range(3)], f32)
+        own = [bool(ey[k] < 0 or (ey[k] == 0 and ex[k] < 0)) for k in range(3)]
+        yy, xx = np.mgrid[y_lo:y_hi + 1, x_lo:x_hi + 1]
+        fxp = xx.astype(f32) + f32(0.5)
+        fyp = yy.astype(f32) + f32(0.5)
+        tu, tv = T[tri, :, 0], T[tri, :, 1]
+
+        def attrs(px, py):
+            b = [(ex[k] * (py - yw[(k + 1) % 3]) - ey[k] * (px - xw[(k + 1) % 3])) * inv_area for k in range(3)]
+            zz = (b[0] * zw[0] + b[1] * zw[1]) + b[2] * zw[2]
+            q = (b[0] * iw[0] + b[1] * iw[1]) + b[2] * iw[2]
+            u = ((b[0] * tu[0] * iw[0] + b[1] * tu[1] * iw[1]) + b[2] * tu[2] * iw[2]) / q
+            v = ((b[0] * tv[0] * iw[0] + b[1] * tv[1] * iw[1]) + b[2] * tv[2] * iw[2]) / q
+            return b, zz, u, v
+
+        with np.errstate(divide="ignore", invalid="ignore"):
+            b, zz, u, v = attrs(fxp, fyp)
+            inside = np.ones(fxp.shape, bool)
+            for k in range(3):
+                inside &= (b[k] > 0) | ((b[k] == 0) & own[k])
+            inside &= (zz >= 0) & (zz <= 1)
+            if not inside.any():
+                continue
+            _, _, ux, vx = attrs(fxp + f32(1.0), fyp)
+            _, _, uy, vy = attrs(fxp, fyp + f32(1.0))
+            dudx, dvdx, dudy, dvdy = (ux - u) * tw, (vx - v) * th, (uy - u) * tw, (vy - v) * th
+            rho = np.maximum(np.sqrt(dudx * dudx + dvdx * dvdx), np.sqrt(dudy * dudy + dvdy * dvdy))
+            lam = np.log2(rho).astype(f32)
+            luma = _bilinear(levels[0], u, v)
+            mini = lam > 0
+            if mini.any():
+                lc = np.minimum(lam, f32(nlev - 1))
+                l0 = np.floor(lc).astype(np.int64)
+                fr = lc - l0.astype(f32)
+                for L in np.unique(l0[mini & inside]):
+                    sel = mini & (l0 == L)
+                    L1 = min(int(L) + 1, nlev - 1)
+                    s0 = _bilinear(levels[int(L)], u, v)
+                    s1 = _bilinear(levels[L1], u, v)
+                    luma = np.where(sel, s0 + (s1 - s0) * fr, luma)
+            colour = (np.clip(luma, 0, 1) * f32(255.0) + f32(0.5)).astype(np.uint32)
+            depth = (zz * f32(16777215.0) + f32(0.5)).astype(np.uint32)
+        frag = (depth << np.uint32(8)) | colour
+        sub = zbuf[y_lo:y_hi + 1, x_lo:x_hi + 1]
+        sub[inside] = np.minimum(sub[inside], frag[inside])
+    return (zbuf & np.uint32(0xFF)).astype(np.uint8)
+
+
+def render_stack(xyz, uv, levels, mvps, width, height):
+    return np.stack([render_mesh(xyz, uv, levels, m, width, height) for m in np.asarray(mvps, f32).reshape(-1, 16)])

@@ -23,7 +23,8 @@ ERR_NOT_READY = -4
 # Every symbol include/nmi_hip.h declares; tests check that the library exports all of them.
 EXPORTED_SYMBOLS = (
     "nmi_params_default", "nmi_create", "nmi_destroy", "nmi_set_stream", "nmi_synchronize", "nmi_eval_pair", "nmi_eval_pair_debug",
-    "nmi_search_grid", "nmi_search_grid_shard", "nmi_warp_homographies", "nmi_warp_stack", "nmi_render_mvp", "nmi_render_points", "nmi_level_create", "nmi_level_run", "nmi_level_destroy", "nmi_stream_create", "nmi_stream_destroy",
+    "nmi_search_grid", "nmi_search_grid_shard", "nmi_warp_homographies", "nmi_warp_stack", "nmi_render_mvp", "nmi_render_points", "nmi_level_create", "nmi_level_run", "nmi_level_destroy", "nmi_texture_create",
+    "nmi_texture_destroy", "nmi_render_mesh", "nmi_stream_create", "nmi_stream_destroy",
     "nmi_stream_submit", "nmi_stream_wait", "nmi_key_pack", "nmi_key_unpack", "nmi_search_grid_rccl",
     "nmi_rccl_unique_id", "nmi_rccl_comm_init", "nmi_rccl_comm_destroy", "nmi_set_profiling", "nmi_last_kernel_ms",
     "nmi_set_option", "nmi_abi_version", "nmi_error_string", "nmi_last_error_detail", "nmi_get_info",
@@ -82,6 +83,9 @@ def load_library(build_if_missing=False):
     lib.nmi_warp_stack.argtypes = [vp, vp, C.POINTER(C.c_double), i32, vp]
     lib.nmi_render_mvp.argtypes = [C.POINTER(RenderParams), f32p, f32p, f32p, f32p, f32p]
     lib.nmi_render_points.argtypes = [vp, vp, vp, C.c_int64, f32p, i32, C.c_float, vp]
+    lib.nmi_texture_create.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
+    lib.nmi_texture_destroy.argtypes = [vp]
+    lib.nmi_render_mesh.argtypes = [vp, vp, vp, C.c_int64, vp, f32p, i32, vp]
     lib.nmi_level_create.argtypes = [vp, vp, vp, C.c_int64, vp, i32, i32, C.c_float, C.POINTER(vp)]
     lib.nmi_level_run.argtypes = [vp, f32p, C.POINTER(C.c_double), i64p, f32p]
     lib.nmi_level_destroy.argtypes = [vp]
@@ -318,6 +322,27 @@ class NmiContext:
             self.synchronize()
         return out
 
+    def render_mesh(self, xyz, uv, texture, mvps, out=None, sync=True):
+        """Rendering<1>::renderToTextureOnGPU without OpenGL: device float32 corner arrays xyz [3T,3], uv [3T,2], an
+        NmiTexture, host MVPs [S,16] -> render stack [S,H,W] u8 on the device (bottom-up rows, background 255)."""
+        import torch
+        for t, cols in ((xyz, 3), (uv, 2)):
+            if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.dim() != 2 or t.shape[1] != cols:
+                raise TypeError("xyz / uv must be contiguous float32 device tensors [3T,3] / [3T,2]")
+        if xyz.shape[0] != uv.shape[0] or xyz.shape[0] % 3:
+            raise ValueError("xyz and uv must hold three corners per triangle")
+        m = np.ascontiguousarray(mvps, np.float32).reshape(-1, 16)
+        S = m.shape[0]
+        if out is None:
+            out = torch.empty((S, self.height, self.width), dtype=torch.uint8, device=self.device)
+        o = self._stack(out, "out")
+        self._order_after_torch()
+        self._check(self._lib.nmi_render_mesh(self._h, xyz.data_ptr(), uv.data_ptr(), xyz.shape[0] // 3, texture._h,
+                                              m.ctypes.data_as(C.POINTER(C.c_float)), S, o.data_ptr()), "nmi_render_mesh")
+        if sync:
+            self.synchronize()
+        return out
+
     def search_grid(self, render_stack, warp_stack, ratings=None):
         """Candidate loop + arg-max (Tracking.cc:1879-1905,1952).  -> (best linear index w*S+s, best score).
 
@@ -372,6 +397,29 @@ class NmiContext:
                                                    Wn, self._ratings_ptr(ratings, Wn, S), comm, C.byref(idx),
                                                    C.byref(sc)), "nmi_search_grid_rccl")
         return int(idx.value), np.float32(sc.value)
+
+
+class NmiTexture:
+    """nmi_texture wrapper: RGB8 image as handed to glTexImage2D -> mip chain -> per-level luma on the device."""
+
+    def __init__(self, ctx, rgb):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        assert rgb.ndim == 3 and rgb.shape[2] == 3
+        self.ctx, self._lib = ctx, ctx._lib
+        self._h = C.c_void_p()
+        ctx._check(self._lib.nmi_texture_create(ctx._h, rgb.ctypes.data_as(C.c_void_p), rgb.shape[1], rgb.shape[0],
+                                                C.byref(self._h)), "nmi_texture_create")
+
+    def close(self):
+        if self._h and self._h.value:
+            self._lib.nmi_texture_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 class NmiLevel:

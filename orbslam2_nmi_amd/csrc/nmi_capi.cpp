@@ -12,6 +12,7 @@
 
 #include <new>
 #include <string>
+#include <vector>
 
 #include "nmi_hip.h"
 #include "nmi_kernels.h"
@@ -262,6 +263,34 @@ int fetch_key(nmi_ctx *ctx, unsigned long long *key)
                                     hipMemcpyDeviceToHost, ctx->stream));
     NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *key = *ctx->h_key;
+    return NMI_OK;
+}
+
+// Uploads `n` floats through a StagingRing slot on the context's stream; *d_out is the device copy (valid for work
+// enqueued on that stream until the slot comes round again).
+int stage_floats(nmi_ctx *ctx, StagingRing &ring, const float *h_src, size_t n, float **d_out)
+{
+    if (n > ring.cap) {
+        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < StagingRing::kSlots; ++i) {
+            if (ring.d[i]) NMI_HIP_TRY(ctx, hipFree(ring.d[i]));
+            if (ring.h[i]) NMI_HIP_TRY(ctx, hipHostFree(ring.h[i]));
+            ring.d[i] = ring.h[i] = nullptr;
+        }
+        ring.cap = 0;
+        for (int i = 0; i < StagingRing::kSlots; ++i) {
+            NMI_HIP_TRY(ctx, hipMalloc((void **)&ring.d[i], n * sizeof(float)));
+            NMI_HIP_TRY(ctx, hipHostMalloc((void **)&ring.h[i], n * sizeof(float), hipHostMallocDefault));
+            if (!ring.ev[i]) NMI_HIP_TRY(ctx, hipEventCreateWithFlags(&ring.ev[i], hipEventDisableTiming));
+        }
+        ring.cap = n;
+    }
+    const int slot = (int)(ring.uses++ % StagingRing::kSlots);
+    NMI_HIP_TRY(ctx, hipEventSynchronize(ring.ev[slot]));
+    memcpy(ring.h[slot], h_src, n * sizeof(float));
+    NMI_HIP_TRY(ctx, hipMemcpyAsync(ring.d[slot], ring.h[slot], n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    NMI_HIP_TRY(ctx, hipEventRecord(ring.ev[slot], ctx->stream));
+    *d_out = ring.d[slot];
     return NMI_OK;
 }
 
@@ -625,29 +654,115 @@ int nmi_render_points(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int6
         NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_zbuf, (size_t)need * sizeof(uint32_t)));
         ctx->zbuf_cap = need;
     }
-    StagingRing &ring = ctx->mvp_ring;
-    if ((size_t)S * 16 > ring.cap) {
-        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        for (int i = 0; i < StagingRing::kSlots; ++i) {
-            if (ring.d[i]) NMI_HIP_TRY(ctx, hipFree(ring.d[i]));
-            if (ring.h[i]) NMI_HIP_TRY(ctx, hipHostFree(ring.h[i]));
-            ring.d[i] = ring.h[i] = nullptr;
-        }
-        ring.cap = 0;
-        for (int i = 0; i < StagingRing::kSlots; ++i) {
-            NMI_HIP_TRY(ctx, hipMalloc((void **)&ring.d[i], (size_t)S * 16 * sizeof(float)));
-            NMI_HIP_TRY(ctx, hipHostMalloc((void **)&ring.h[i], (size_t)S * 16 * sizeof(float), hipHostMallocDefault));
-            if (!ring.ev[i]) NMI_HIP_TRY(ctx, hipEventCreateWithFlags(&ring.ev[i], hipEventDisableTiming));
-        }
-        ring.cap = (size_t)S * 16;
-    }
-    const int slot = (int)(ring.uses++ % StagingRing::kSlots);
-    NMI_HIP_TRY(ctx, hipEventSynchronize(ring.ev[slot]));
-    memcpy(ring.h[slot], h_mvps, (size_t)S * 16 * sizeof(float));
-    NMI_HIP_TRY(ctx, hipMemcpyAsync(ring.d[slot], ring.h[slot], (size_t)S * 16 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    NMI_HIP_TRY(ctx, hipEventRecord(ring.ev[slot], ctx->stream));
-    NMI_HIP_TRY(ctx, nmi::launch_render_points(d_xyz, d_red, n_points, ring.d[slot], S, ctx->d_zbuf, d_render_stack, ctx->params.width,
+    float *d_mvps = nullptr;
+    const int src = stage_floats(ctx, ctx->mvp_ring, h_mvps, (size_t)S * 16, &d_mvps);
+    if (src != NMI_OK) return src;
+    NMI_HIP_TRY(ctx, nmi::launch_render_points(d_xyz, d_red, n_points, d_mvps, S, ctx->d_zbuf, d_render_stack, ctx->params.width,
                                                ctx->params.height, size, ctx->stream));
+    return NMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Textured-mesh renderer: texture object (mip chain -> per-level luma on the device) and the draw call.
+// ---------------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+struct nmi_texture {
+    nmi_ctx *ctx = nullptr;
+    float *d_luma = nullptr;
+    int levels = 0;
+    int w[16] = {}, h[16] = {};
+    long long off[16] = {};
+};
+
+extern "C" {
+
+int nmi_texture_destroy(nmi_texture *tex)
+{
+    if (!tex) return NMI_OK;
+    DeviceGuard guard(tex->ctx->device);
+    (void)hipStreamSynchronize(tex->ctx->stream);
+    if (tex->d_luma) (void)hipFree(tex->d_luma);
+    delete tex;
+    return NMI_OK;
+}
+
+int nmi_texture_create(nmi_ctx *ctx, const uint8_t *h_rgb, int32_t tw, int32_t th, nmi_texture **out)
+{
+    if (!ctx || !h_rgb || !out || tw <= 0 || th <= 0 || tw > 32768 || th > 32768) return NMI_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    ctx->detail.clear();
+    nmi_texture *tex = new (std::nothrow) nmi_texture;
+    if (!tex) return NMI_ERR_INVALID_ARGUMENT;
+    tex->ctx = ctx;
+    // level sizes: max(1, floor(size / 2)) until 1x1 (OpenGL 3.3, 3.8.14)
+    long long total = 0;
+    int lw = tw, lh = th;
+    for (;;) {
+        tex->w[tex->levels] = lw;
+        tex->h[tex->levels] = lh;
+        tex->off[tex->levels] = total;
+        total += (long long)lw * lh;
+        ++tex->levels;
+        if ((lw == 1 && lh == 1) || tex->levels == 16) break;
+        lw = lw > 1 ? lw / 2 : 1;
+        lh = lh > 1 ? lh / 2 : 1;
+    }
+    std::vector<uint8_t> cur(h_rgb, h_rgb + (size_t)tw * th * 3), next;
+    std::vector<float> luma((size_t)total);
+    for (int l = 0; l < tex->levels; ++l) {
+        const int w = tex->w[l], h = tex->h[l];
+        float *dst = luma.data() + tex->off[l];
+        for (size_t i = 0; i < (size_t)w * h; ++i)  // fragment shader :16, on normalised 8-bit channels
+            dst[i] = 0.299f * ((float)cur[i * 3] / 255.0f) + 0.587f * ((float)cur[i * 3 + 1] / 255.0f) + 0.114f * ((float)cur[i * 3 + 2] / 255.0f);
+        if (l + 1 == tex->levels) break;
+        const int nw = tex->w[l + 1], nh = tex->h[l + 1];
+        next.assign((size_t)nw * nh * 3, 0);
+        for (int y = 0; y < nh; ++y)
+            for (int x = 0; x < nw; ++x)
+                for (int c = 0; c < 3; ++c) {  // 2x2 box filter, rounded to 8 bits per level
+                    const int x0 = 2 * x < w ? 2 * x : w - 1, x1 = 2 * x + 1 < w ? 2 * x + 1 : w - 1;
+                    const int y0 = 2 * y < h ? 2 * y : h - 1, y1 = 2 * y + 1 < h ? 2 * y + 1 : h - 1;
+                    const int sum = cur[((size_t)y0 * w + x0) * 3 + c] + cur[((size_t)y0 * w + x1) * 3 + c] +
+                                    cur[((size_t)y1 * w + x0) * 3 + c] + cur[((size_t)y1 * w + x1) * 3 + c];
+                    next[((size_t)y * nw + x) * 3 + c] = (uint8_t)((sum + 2) / 4);
+                }
+        cur.swap(next);
+    }
+    DeviceGuard guard(ctx->device);
+    hipError_t e = hipMalloc((void **)&tex->d_luma, (size_t)total * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(tex->d_luma, luma.data(), (size_t)total * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        const int rc = hip_fail(ctx, e, "nmi_texture_create");
+        nmi_texture_destroy(tex);
+        return rc;
+    }
+    *out = tex;
+    return NMI_OK;
+}
+
+int nmi_render_mesh(nmi_ctx *ctx, const float *d_xyz, const float *d_uv, int64_t n_triangles, const nmi_texture *tex,
+                    const float *h_mvps, int32_t S, uint8_t *d_render_stack)
+{
+    if (!ctx || !tex || tex->ctx != ctx || !h_mvps || !d_render_stack || S <= 0 || n_triangles < 0 ||
+        (n_triangles > 0 && (!d_xyz || !d_uv)))
+        return NMI_ERR_INVALID_ARGUMENT;
+    ctx->detail.clear();
+    DeviceGuard guard(ctx->device);
+    const int64_t need = (int64_t)S * ctx->npix;
+    if (need > ctx->zbuf_cap) {
+        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_zbuf) NMI_HIP_TRY(ctx, hipFree(ctx->d_zbuf));
+        ctx->d_zbuf = nullptr;
+        ctx->zbuf_cap = 0;
+        NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_zbuf, (size_t)need * sizeof(uint32_t)));
+        ctx->zbuf_cap = need;
+    }
+    float *d_mvps = nullptr;
+    int rc = stage_floats(ctx, ctx->mvp_ring, h_mvps, (size_t)S * 16, &d_mvps);
+    if (rc != NMI_OK) return rc;
+    NMI_HIP_TRY(ctx, nmi::launch_render_mesh(d_xyz, d_uv, n_triangles, tex->d_luma, tex->levels, tex->w, tex->h, tex->off, d_mvps, S,
+                                             ctx->d_zbuf, d_render_stack, ctx->params.width, ctx->params.height, ctx->stream));
     return NMI_OK;
 }
 

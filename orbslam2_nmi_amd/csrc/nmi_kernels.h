@@ -51,6 +51,9 @@ size_t grid_kernel_scratch_bytes(int workgroups);
 hipError_t launch_warp(const uint8_t *frame, const float *coeffs /*[Wn][9] inverse maps*/, uint8_t *out, int width,
                        int height, int Wn, hipStream_t stream);
 
+hipError_t launch_render_mesh(const float *xyz, const float *uv, long long ntri, const float *luma, int levels, const int *lw,
+                              const int *lh, const long long *loff, const float *mvps /*[S][16]*/, int S, uint32_t *zbuf /*[S][H][W]*/,
+                              uint8_t *out, int width, int height, hipStream_t stream);
 size_t render_zbuf_words(int S, int width, int height, int size);
 hipError_t launch_render_points(const float *xyz, const float *red, long long npoints, const float *mvps /*[S][16] column-major*/,
                                 int S, uint32_t *zbuf /*[render_zbuf_words]*/, uint8_t *out, int width, int height, int size, hipStream_t stream);

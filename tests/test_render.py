@@ -148,3 +148,106 @@ def test_gpu_level_graph_equals_separate_calls():
                 rs = ctx.render_points(dx, dr, mvps, 3.0)
                 ws = ctx.warp_stack(frame, Ms)
                 assert got == ctx.search_grid(rs, ws), lvl
+
+
+# ---- textured-mesh mode (nmi_prop_RENDER 1) --------------------------------------------------------------------------
+from oracle import mesh_oracle_np as mo  # noqa: E402
+
+
+def test_mip_chain_and_luma():
+    rng = np.random.default_rng(1)
+    rgb = rng.integers(0, 256, (8, 16, 3), dtype=np.uint8)
+    lv = mo.mip_luma(rgb)
+    assert [l.shape for l in lv] == [(8, 16), (4, 8), (2, 4), (1, 2), (1, 1)]
+    exp0 = 0.299 * rgb[..., 0] / 255 + 0.587 * rgb[..., 1] / 255 + 0.114 * rgb[..., 2] / 255   # byte 0 weighs 0.299 (shader :16)
+    assert np.allclose(lv[0], exp0, atol=1e-6)
+    box = (rgb[0:2, 0:2].astype(int).sum(axis=(0, 1)) + 2) // 4
+    assert np.allclose(lv[1][0, 0], 0.299 * box[0] / 255 + 0.587 * box[1] / 255 + 0.114 * box[2] / 255, atol=1e-6)
+
+
+def plane_mesh(w, h, depth=10.0, nx=24, ny=18, seed=3):
+    """A textured plane as nx x ny quads (two counter-clockwise triangles each, seen from the origin looking along +z with
+    up = -y), plus an occluder nearer to the camera, a back-facing triangle and one partly outside the frustum."""
+    rp = params(w, h)
+    us = np.linspace(-0.3 * w, 1.3 * w, nx + 1)
+    vs = np.linspace(-0.3 * h, 1.3 * h, ny + 1)
+    def world(u, v, d):
+        return [(u - rp.cx) / rp.fx * d, (v - rp.cy) / rp.fy * d, d]
+    tris, uvs = [], []
+    for j in range(ny):
+        for i in range(nx):
+            p00, p10, p01, p11 = world(us[i], vs[j], depth), world(us[i + 1], vs[j], depth), world(us[i], vs[j + 1], depth), world(us[i + 1], vs[j + 1], depth)
+            t00, t10, t01, t11 = (i / nx, j / ny), ((i + 1) / nx, j / ny), (i / nx, (j + 1) / ny), ((i + 1) / nx, (j + 1) / ny)
+            tris += [p00, p10, p11, p00, p11, p01]
+            uvs += [t00, t10, t11, t00, t11, t01]
+    tris += [world(0.3 * w, 0.3 * h, 7.0), world(0.6 * w, 0.35 * h, 7.0), world(0.45 * w, 0.7 * h, 8.0)]       # occluder
+    uvs += [(0.1, 0.1), (2.4, 0.2), (1.2, 2.9)]                                                                 # repeats (GL_REPEAT), minified
+    tris += [world(0.7 * w, 0.2 * h, 6.0), world(0.8 * w, 0.4 * h, 6.0), world(0.9 * w, 0.2 * h, 6.0)]          # opposite winding
+    uvs += [(0, 0), (1, 1), (1, 0)]
+    tris += [world(0.9 * w, 0.8 * h, 9.0), world(1.6 * w, 0.85 * h, 9.0), world(1.2 * w, 1.5 * h, 9.0)]         # leaves the frustum
+    uvs += [(0, 0), (1, 0), (0.5, 1)]
+    # the camera of this test mirrors x (rendering.hpp:196-202 puts fx / -cx on the diagonal, and up = -y): corner order as
+    # written above is clockwise on screen, so reverse every triangle to make the plane front-facing
+    xyz = np.array(tris, np.float32).reshape(-1, 3, 3)[:, ::-1].reshape(-1, 3).copy()
+    uv = np.array(uvs, np.float32).reshape(-1, 3, 2)[:, ::-1].reshape(-1, 2).copy()
+    B = sy.scene(128, 128, seed)
+    rgb = np.stack([B, np.roll(B, 7, 0), np.roll(B, 11, 1)], -1).astype(np.uint8)
+    return xyz, uv, rgb, rp
+
+
+def test_mesh_twin_sanity():
+    w, h = 96, 72
+    xyz, uv, rgb, rp = plane_mesh(w, h)
+    lv = mo.mip_luma(rgb)
+    m = capi.render_mvp(rp, (0, 0, 0), (0, 0, 1), (0, -1, 0), (0, 0, 0))
+    img = mo.render_mesh(xyz, uv, lv, m, w, h)
+    assert (img != 255).mean() > 0.97                       # the plane covers the view (quads face the camera)
+    flipped = xyz.reshape(-1, 3, 3)[:, ::-1].reshape(-1, 3)  # reverse every winding: everything is culled but the one back-facer
+    img2 = mo.render_mesh(flipped, uv.reshape(-1, 3, 2)[:, ::-1].reshape(-1, 2), lv, m, w, h)
+    assert 0 < (img2 != 255).mean() < 0.05
+
+
+@pytest.mark.gpu
+def test_gpu_mesh_vs_twin():
+    torch = pytest.importorskip("torch")
+    import orbslam2_nmi_amd as nmi
+    w, h = 160, 120
+    xyz, uv, rgb, rp = plane_mesh(w, h)
+    mvps = np.stack([capi.render_mvp(rp, (0, 0, 0), (0, 0, 1), (0, -1, 0), t) for t in ((0, 0, 0), (0.4, -0.3, 1.0), (-0.8, 0.2, -3.0))])
+    with nmi.NmiContext(w, h) as ctx, nmi.NmiTexture(ctx, rgb) as tex:
+        got = ctx.render_mesh(torch.from_numpy(xyz).cuda(), torch.from_numpy(uv).cuda(), tex, mvps).cpu().numpy()
+    exp = mo.render_stack(xyz, uv, mo.mip_luma(rgb), mvps, w, h)
+    assert got.shape == exp.shape
+    diff = np.abs(got.astype(int) - exp.astype(int))
+    # coverage / depth decisions identical; the texture LOD goes through log2f, whose last bit may differ between the
+    # device library and numpy, so a handful of pixels may differ by one grey level
+    assert ((got == 255) == (exp == 255)).all()
+    assert diff.max() <= 1 and (diff != 0).mean() < 2e-3, (diff.max(), (diff != 0).mean())
+
+
+@pytest.mark.gpu
+def test_gpu_mesh_to_winner_end_to_end():
+    """mesh + texture + pose -> device render stack for a 3x3x1 translation grid; the frame is the mesh seen from a
+    displaced pose (other gamma + noise); the search picks the nearest cell."""
+    torch = pytest.importorskip("torch")
+    import orbslam2_nmi_amd as nmi
+    from orbslam2_nmi_amd import hostapi as H
+    w, h = 320, 240
+    xyz, uv, rgb, rp = plane_mesh(w, h, nx=40, ny=30)
+    Twc = np.eye(4, dtype=np.float32)
+    Twc[:3, 1] = [0, -1, 0]
+    grid = H.SearchKernel.make([3, 3, 1, 1, 1, 1], [0.3, 0.3, 0.5, 0.02, 0.02, 0.05])
+    pos, look, up = Twc[:3, 3], Twc[:3, 3] + Twc[:3, 2], Twc[:3, 1]
+    cells = [(sx, sy_, 0) for sy_ in range(3) for sx in range(3)]
+    mvps = np.stack([capi.render_mvp(rp, pos, look, up, H.calculate_translation(Twc, grid, *c)) for c in cells])
+    truth = (0, 2, 0)
+    t_true = H.calculate_translation(Twc, grid, *truth) * np.float32(0.85)
+    with nmi.NmiContext(w, h) as ctx, nmi.NmiTexture(ctx, rgb) as tex:
+        dx, du = torch.from_numpy(xyz).cuda(), torch.from_numpy(uv).cuda()
+        rs = ctx.render_mesh(dx, du, tex, mvps)
+        fr = ctx.render_mesh(dx, du, tex, capi.render_mvp(rp, pos, look, up, t_true)[None])[0]
+        noise = torch.from_numpy(np.random.default_rng(2).normal(0, 6, (h, w)).astype(np.float32)).cuda()
+        frame = torch.clamp(torch.round(255.0 * (torch.flip(fr, dims=[0]).float() / 255.0) ** 0.7 + noise), 0, 255).to(torch.uint8).contiguous()
+        t = torch.zeros(1, 9, device="cuda")
+        idx, best = ctx.search_grid(rs, frame[None], t)
+    assert cells[idx] == truth and best > 1.3 * np.sort(t.cpu().numpy().reshape(-1))[-2]
