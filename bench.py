@@ -205,7 +205,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--blocking", action="store_true", help="latency mode: one blocking search per step")
-    ap.add_argument("--streams", type=int, default=2, help="searches kept in flight in throughput mode (contexts / streams)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="searches kept in flight in throughput mode (one context + stream each); 2 fills the idle CUs of the "
+                         "85%%-full last round (+5%%) but makes per-launch durations overlap, so the default stays 1")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the N>1 code path (process group, async all-reduce per step) even with one rank")
@@ -304,8 +306,12 @@ def main():
             if res[0] != planted_global:
                 sys.exit(f"rank {rank}: wrong winner {res} (expected index {planted_global})")
 
+    region = {}
+
     def run_async(n):
         works = []
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(streams[0])  # HIP events on the launch stream bracket the kernels of the timed region
         for i in range(n):
             slot = keys[i:i + 1]
             k = i % n_streams
@@ -314,6 +320,8 @@ def main():
             if dist is not None:
                 works.append(dist.all_reduce(slot, op=dist.ReduceOp.MAX, async_op=True))  # 8 bytes over RCCL/xGMI
         torch.cuda.set_stream(streams[0])
+        ev1.record(streams[0])
+        region["events"] = (ev0, ev1, n)
         for wk in works:
             wk.wait()
         for st_ in streams[1:]:
@@ -360,7 +368,16 @@ def main():
             ctx.search_grid_shard(rs, s_offset, S_total, ws, key_out=key, blocking=True)
         durs.append(ctx.last_kernel_ms())
     ctx.set_profiling(False)
-    kernel_ms = float(np.mean(durs))
+    kernel_ms_exclusive = float(np.mean(durs))
+    # Average launch duration over the timed region itself: HIP events recorded on the launch stream before the first and
+    # after the last of the K back-to-back launches (one stream: the launches run one after the other, so this is the
+    # kernel's duration plus the ~1 us hand-over between launches).  With several streams the launches overlap and a
+    # per-launch duration is not defined: the exclusive figure (one launch at a time, events around it) is used.
+    if not args.blocking and n_streams == 1 and "events" in region:
+        e0, e1, n_timed = region["events"]
+        kernel_ms = e0.elapsed_time(e1) / n_timed
+    else:
+        kernel_ms = kernel_ms_exclusive
 
     if rank == 0:
         evals_per_step = S_total * WN
@@ -390,7 +407,7 @@ def main():
                        "collective": "none" if dist is None else "8-byte MAX all-reduce (RCCL)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_pmc_traffic(),
-                         "kernel": "nmi_grid_kernel", "kernel_ms": kernel_ms,
+                         "kernel": "nmi_grid_kernel", "kernel_ms": kernel_ms, "kernel_ms_exclusive": kernel_ms_exclusive,
                          "algorithmic_bytes_per_launch": per_launch_evals * algorithmic_bytes_per_eval(WIDTH, HEIGHT)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -9,6 +9,7 @@ ROOT=$PWD
 mkdir -p "$OUT"
 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" || exit 1
 python3 bench.py --blocking --no-cpu-baseline > "$OUT/bench_blocking.json" 2>> "$OUT/bench.err" || exit 1
+python3 bench.py --streams 2 --no-cpu-baseline > "$OUT/bench_2streams.json" 2>> "$OUT/bench.err" || exit 1
 python3 bench.py --config stream > "$OUT/bench_stream.json" 2>> "$OUT/bench.err" || exit 1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --steps 50 --warmup 5 --no-cpu-baseline > "$OUT/trace.log" 2>&1 || exit 1
