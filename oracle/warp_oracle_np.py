@@ -5,7 +5,7 @@ cv::cuda::warpPerspective(src, dst, M, size) with the defaults INTER_LINEAR / BO
 OpenCV 3.4.0 (CUDA_Functions.vcxproj / Localization.vcxproj dependency, not vendored in the reference, absent in this
 image) does the arithmetic; this file follows its published device path from the library's sources as remembered:
 invert M on the host in double, pass 9 floats, per destination pixel
-    xs = (c0*x + c1*y + c2) / (c6*x + c7*y + c8),  ys = (c3*x + c4*y + c5) / (c6*x + c7*y + c8)     (fp32)
+    coeff = 1 / (c6*x + c7*y + c8);  xs = coeff * (c0*x + c1*y + c2),  ys = coeff * (c3*x + c4*y + c5)     (fp32)
     LinearFilter: x1 = floor(xs), y1 = floor(ys); out = s(y1,x1)*((x2-xs)*(y2-ys)) + s(y1,x2)*((xs-x1)*(y2-ys))
                   + s(y2,x1)*((x2-xs)*(ys-y1)) + s(y2,x2)*((xs-x1)*(ys-y1));  border taps = 0
     saturate_cast<uchar>: round to nearest even, clamp to [0, 255].
@@ -38,9 +38,9 @@ def warp_perspective(img, M, coeffs=None):
     yy, xx = np.mgrid[0:h, 0:w]
     fx, fy = xx.astype(f32), yy.astype(f32)
     with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
-        den = (c[6] * fx + c[7] * fy) + c[8]
-        xs = ((c[0] * fx + c[1] * fy) + c[2]) / den
-        ys = ((c[3] * fx + c[4] * fy) + c[5]) / den
+        coeff = f32(1.0) / ((c[6] * fx + c[7] * fy) + c[8])
+        xs = coeff * ((c[0] * fx + c[1] * fy) + c[2])
+        ys = coeff * ((c[3] * fx + c[4] * fy) + c[5])
         inside = (xs > f32(-2)) & (xs < f32(w + 1)) & (ys > f32(-2)) & (ys < f32(h + 1))
         xs = np.where(inside, xs, f32(-10))
         ys = np.where(inside, ys, f32(-10))

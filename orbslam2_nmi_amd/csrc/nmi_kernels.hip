@@ -940,8 +940,8 @@ size_t grid_kernel_scratch_bytes(int workgroups) { return (size_t)workgroups * 2
 // Warp-stack producer: Image::calculateWarping, Thirdparty/Localization/image.cpp:115-128 --
 // Wn calls of cv::cuda::warpPerspective(frame, warped[w], K*R*K^-1, size) with the defaults INTER_LINEAR,
 // BORDER_CONSTANT(0), forward matrix.  OpenCV 3.4.0 is not vendored in the reference and absent here, so the
-// arithmetic below follows OpenCV's published device path (inverse matrix as 9 floats; source coordinate
-// (c0*x+c1*y+c2)/(c6*x+c7*y+c8) in fp32; bilinear LinearFilter with floor(), the four taps accumulated in the
+// arithmetic below follows OpenCV's published device path (inverse matrix as 9 floats; coeff = 1/(c6*x+c7*y+c8),
+// source coordinate coeff*(c0*x+c1*y+c2) in fp32; bilinear LinearFilter with floor(), the four taps accumulated in the
 // order (y1,x1) (y1,x2) (y2,x1) (y2,x2); saturate_cast<uchar> = round to nearest even) -- parity unpinned.
 // One thread produces 4 horizontally adjacent pixels of one warp and stores them as one dword.
 __device__ __forceinline__ float warp_tap(const uint8_t *__restrict__ src, int w, int h, int x, int y)
@@ -965,18 +965,27 @@ __global__ __launch_bounds__(256) void nmi_warp_kernel(const uint8_t *__restrict
         uint32_t v = 0;
         if (x < width) {
             const float fx = (float)x, fy = (float)y;
-            const float den = c[6] * fx + c[7] * fy + c[8];
-            const float xs = (c[0] * fx + c[1] * fy + c[2]) / den;
-            const float ys = (c[3] * fx + c[4] * fy + c[5]) / den;
+            // OpenCV's device transform: one reciprocal of the homogeneous coordinate, two multiplies
+            const float coeff = 1.0f / (c[6] * fx + c[7] * fy + c[8]);
+            const float xs = coeff * (c[0] * fx + c[1] * fy + c[2]);
+            const float ys = coeff * (c[3] * fx + c[4] * fy + c[5]);
             // coordinates far outside the frame (or non-finite) see only the constant border
             float acc = 0.0f;
             if (xs > -2.0f && xs < (float)(width + 1) && ys > -2.0f && ys < (float)(height + 1)) {
                 const int x1 = (int)floorf(xs), y1 = (int)floorf(ys);
                 const int x2 = x1 + 1, y2 = y1 + 1;
-                acc = acc + warp_tap(frame, width, height, x1, y1) * (((float)x2 - xs) * ((float)y2 - ys));
-                acc = acc + warp_tap(frame, width, height, x2, y1) * ((xs - (float)x1) * ((float)y2 - ys));
-                acc = acc + warp_tap(frame, width, height, x1, y2) * (((float)x2 - xs) * (ys - (float)y1));
-                acc = acc + warp_tap(frame, width, height, x2, y2) * ((xs - (float)x1) * (ys - (float)y1));
+                float t11, t21, t12, t22;
+                if (x1 >= 0 && x2 < width && y1 >= 0 && y2 < height) {  // all four taps inside: no per-tap border test
+                    const uint8_t *p = frame + y1 * width + x1;
+                    t11 = (float)p[0], t21 = (float)p[1], t12 = (float)p[width], t22 = (float)p[width + 1];
+                } else {
+                    t11 = warp_tap(frame, width, height, x1, y1), t21 = warp_tap(frame, width, height, x2, y1);
+                    t12 = warp_tap(frame, width, height, x1, y2), t22 = warp_tap(frame, width, height, x2, y2);
+                }
+                acc = acc + t11 * (((float)x2 - xs) * ((float)y2 - ys));
+                acc = acc + t21 * ((xs - (float)x1) * ((float)y2 - ys));
+                acc = acc + t12 * (((float)x2 - xs) * (ys - (float)y1));
+                acc = acc + t22 * ((xs - (float)x1) * (ys - (float)y1));
             }
             const float r = rintf(acc);
             v = r <= 0.0f ? 0u : (r >= 255.0f ? 255u : (uint32_t)r);

@@ -76,25 +76,29 @@ public:
     void resetBest() { setBest(-1, -1, -1, -1, -1, -1, 0); }
     void reset() { from_c(blank()); }
 
-    int getNumSynthX() { return numSynthX; }
-    int getNumSynthY() { return numSynthY; }
-    int getNumSynthZ() { return numSynthZ; }
-    int getNumWarpX() { return numWarpX; }
-    int getNumWarpY() { return numWarpY; }
-    int getNumWarpZ() { return numWarpZ; }
-    float getStepX() { return stepX; }
-    float getStepY() { return stepY; }
-    float getStepZ() { return stepZ; }
-    float getStepRadX() { return stepRadX; }
-    float getStepRadY() { return stepRadY; }
-    float getStepRadZ() { return stepRadZ; }
-    int getBestSynthX() { return bestSynthX; }
-    int getBestSynthY() { return bestSynthY; }
-    int getBestSynthZ() { return bestSynthZ; }
-    int getBestWarpX() { return bestWarpX; }
-    int getBestWarpY() { return bestWarpY; }
-    int getBestWarpZ() { return bestWarpZ; }
-    float getNmi() { return NMI; }
+    // the reference's 19 read accessors (nmiSearchKernel.hpp:66-84), one per public field
+#define NMI_SK_GET(type, Name, field) \
+    type get##Name() { return field; }
+    NMI_SK_GET(int, NumSynthX, numSynthX)
+    NMI_SK_GET(int, NumSynthY, numSynthY)
+    NMI_SK_GET(int, NumSynthZ, numSynthZ)
+    NMI_SK_GET(int, NumWarpX, numWarpX)
+    NMI_SK_GET(int, NumWarpY, numWarpY)
+    NMI_SK_GET(int, NumWarpZ, numWarpZ)
+    NMI_SK_GET(float, StepX, stepX)
+    NMI_SK_GET(float, StepY, stepY)
+    NMI_SK_GET(float, StepZ, stepZ)
+    NMI_SK_GET(float, StepRadX, stepRadX)
+    NMI_SK_GET(float, StepRadY, stepRadY)
+    NMI_SK_GET(float, StepRadZ, stepRadZ)
+    NMI_SK_GET(int, BestSynthX, bestSynthX)
+    NMI_SK_GET(int, BestSynthY, bestSynthY)
+    NMI_SK_GET(int, BestSynthZ, bestSynthZ)
+    NMI_SK_GET(int, BestWarpX, bestWarpX)
+    NMI_SK_GET(int, BestWarpY, bestWarpY)
+    NMI_SK_GET(int, BestWarpZ, bestWarpZ)
+    NMI_SK_GET(float, Nmi, NMI)
+#undef NMI_SK_GET
 
     nmi_search_kernel to_c() const
     {
