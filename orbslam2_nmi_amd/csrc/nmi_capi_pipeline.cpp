@@ -1,0 +1,322 @@
+// nmi_capi_pipeline.cpp -- C ABI of the composed forms: one search level as a captured HIP graph (nmi_level_*) and the
+// double-buffered streaming pipeline (nmi_stream_*).  Declared in include/nmi_hip.h.
+#include "nmi_ctx.h"
+
+using namespace nmi_internal;
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------------------
+// One search level as a captured HIP graph: cloud -> S renders, frame -> Wn warps, grid search, winner to the host.
+// Seven dependent operations (two parameter uploads, clear, splat, resolve, warp, key reset + search, winner copy)
+// replay with one hipGraphLaunch; only the pinned parameter buffers change between replays.
+// ---------------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+struct nmi_level {
+    nmi_ctx *ctx = nullptr;
+    int S = 0, Wn = 0, size = 1;
+    uint8_t *d_renders = nullptr, *d_warps = nullptr;
+    uint32_t *d_zbuf = nullptr;
+    float *d_mvps = nullptr, *h_mvps = nullptr, *d_coeffs = nullptr, *h_coeffs = nullptr;
+    int *d_order = nullptr;
+    unsigned long long *d_key = nullptr, *h_key = nullptr;
+    unsigned int *d_done = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+extern "C" {
+
+int nmi_level_destroy(nmi_level *lv)
+{
+    if (!lv) return NMI_OK;
+    DeviceGuard guard(lv->ctx->device);
+    (void)hipStreamSynchronize(lv->ctx->stream);
+    if (lv->exec) (void)hipGraphExecDestroy(lv->exec);
+    if (lv->graph) (void)hipGraphDestroy(lv->graph);
+    void *dev[] = {lv->d_renders, lv->d_warps, lv->d_zbuf, lv->d_mvps, lv->d_coeffs, lv->d_order, lv->d_key, lv->d_done};
+    for (void *q : dev)
+        if (q) (void)hipFree(q);
+    void *host[] = {lv->h_mvps, lv->h_coeffs, lv->h_key};
+    for (void *q : host)
+        if (q) (void)hipHostFree(q);
+    delete lv;
+    return NMI_OK;
+}
+
+int nmi_level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int64_t n_points, const uint8_t *d_frame, int32_t S,
+                     int32_t Wn, float point_size, nmi_level **out)
+{
+    if (!ctx || !out || !d_frame || S <= 0 || Wn <= 0 || n_points < 0 || (n_points > 0 && (!d_xyz || !d_red)))
+        return NMI_ERR_INVALID_ARGUMENT;
+    if (!ctx->params.use_bg) return NMI_ERR_UNSUPPORTED;
+    *out = nullptr;
+    ctx->detail.clear();
+    DeviceGuard guard(ctx->device);
+    nmi_level *lv = new (std::nothrow) nmi_level;
+    if (!lv) return NMI_ERR_INVALID_ARGUMENT;
+    lv->ctx = ctx;
+    lv->S = S;
+    lv->Wn = Wn;
+    int size = (int)floorf(point_size + 0.5f);
+    lv->size = size < 1 ? 1 : (size > 64 ? 64 : size);
+    const nmi_params &p = ctx->params;
+    const size_t npix = (size_t)ctx->npix;
+    const int64_t total = (int64_t)S * Wn;
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t r) {
+        if (e == hipSuccess) e = r;
+        return r == hipSuccess;
+    };
+    ok(hipMalloc((void **)&lv->d_renders, npix * S));
+    ok(hipMalloc((void **)&lv->d_warps, npix * Wn));
+    ok(hipMalloc((void **)&lv->d_zbuf, nmi::render_zbuf_words(S, p.width, p.height, lv->size) * sizeof(uint32_t)));
+    ok(hipMalloc((void **)&lv->d_mvps, (size_t)S * 16 * sizeof(float)));
+    ok(hipMalloc((void **)&lv->d_coeffs, (size_t)Wn * 9 * sizeof(float)));
+    ok(hipMalloc((void **)&lv->d_order, (size_t)total * sizeof(int)));
+    ok(hipMalloc((void **)&lv->d_key, sizeof(unsigned long long)));
+    ok(hipMalloc((void **)&lv->d_done, sizeof(unsigned int)));
+    ok(hipHostMalloc((void **)&lv->h_mvps, (size_t)S * 16 * sizeof(float), hipHostMallocDefault));
+    ok(hipHostMalloc((void **)&lv->h_coeffs, (size_t)Wn * 9 * sizeof(float), hipHostMallocDefault));
+    ok(hipHostMalloc((void **)&lv->h_key, sizeof(unsigned long long), hipHostMallocDefault));
+    int *order = e == hipSuccess ? new (std::nothrow) int[(size_t)total] : nullptr;
+    if (e != hipSuccess || !order) {
+        const int rc = e != hipSuccess ? hip_fail(ctx, e, "nmi_level_create") : NMI_ERR_INVALID_ARGUMENT;
+        nmi_level_destroy(lv);
+        return rc;
+    }
+    build_order(S, Wn, order);
+    ok(hipMemcpy(lv->d_order, order, (size_t)total * sizeof(int), hipMemcpyHostToDevice));
+    delete[] order;
+    ok(hipMemset(lv->d_done, 0, sizeof(unsigned int)));
+    memset(lv->h_mvps, 0, (size_t)S * 16 * sizeof(float));
+    memset(lv->h_coeffs, 0, (size_t)Wn * 9 * sizeof(float));
+    ok(hipDeviceSynchronize());
+
+    nmi::GridArgs a{};
+    a.render_stack = lv->d_renders;
+    a.warp_stack = lv->d_warps;
+    a.S_local = S;
+    a.Wn = Wn;
+    a.s_offset = 0;
+    a.S_total = S;
+    a.width = p.width;
+    a.height = p.height;
+    a.npix = ctx->npix;
+    a.vec_ok = (p.width % 16 == 0) && (((uintptr_t)lv->d_renders | (uintptr_t)lv->d_warps) % 16 == 0);
+    a.chunks_per_row = a.vec_ok ? p.width / 16 : 1;
+    a.cpr_magic = a.chunks_per_row > 1 ? (uint32_t)((0x100000000ull + a.chunks_per_row - 1) / a.chunks_per_row) : 0u;
+    a.shift = ctx->shift;
+    a.mode = p.mode;
+    a.flip = p.render_bottom_up ? 1 : 0;
+    a.table = ctx->table;
+    a.order = lv->d_order;
+    a.key = lv->d_key;        // reset by a memset node before every replay (the ping-pong of plain launches needs
+    a.reset_key = nullptr;    // alternating arguments, which a replayed graph does not have)
+    a.done = lv->d_done;
+    a.hist_variant = 3;
+    a.phase_mask = 3;
+    const int cap = ctx->workgroups > 0 ? ctx->workgroups : ctx->compute_units;
+    const int workgroups = (int)(total < cap ? total : cap);
+
+    hipStream_t st = ctx->stream;
+    if (ok(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal))) {
+        ok(hipMemcpyAsync(lv->d_mvps, lv->h_mvps, (size_t)S * 16 * sizeof(float), hipMemcpyHostToDevice, st));
+        ok(nmi::launch_render_points(d_xyz, d_red, n_points, lv->d_mvps, S, lv->d_zbuf, lv->d_renders, p.width, p.height, lv->size, st));
+        ok(hipMemcpyAsync(lv->d_coeffs, lv->h_coeffs, (size_t)Wn * 9 * sizeof(float), hipMemcpyHostToDevice, st));
+        ok(nmi::launch_warp(d_frame, lv->d_coeffs, lv->d_warps, p.width, p.height, Wn, st));
+        ok(hipMemsetAsync(lv->d_key, 0, sizeof(unsigned long long), st));
+        ok(nmi::launch_grid(a, workgroups, true, st));
+        ok(hipMemcpyAsync(lv->h_key, lv->d_key, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        hipError_t ec = hipStreamEndCapture(st, &lv->graph);
+        ok(ec);
+    }
+    if (e == hipSuccess) ok(hipGraphInstantiate(&lv->exec, lv->graph, nullptr, nullptr, 0));
+    if (e != hipSuccess) {
+        const int rc = hip_fail(ctx, e, "nmi_level_create (graph capture)");
+        nmi_level_destroy(lv);
+        return rc;
+    }
+    *out = lv;
+    return NMI_OK;
+}
+
+int nmi_level_run(nmi_level *lv, const float *h_mvps, const double *h_forward, int64_t *h_best_index, float *h_best_score)
+{
+    if (!lv || !h_mvps || !h_forward) return NMI_ERR_INVALID_ARGUMENT;
+    nmi_ctx *ctx = lv->ctx;
+    ctx->detail.clear();
+    DeviceGuard guard(ctx->device);
+    // the previous replay has completed (this call is blocking), so the pinned parameter buffers are free to rewrite
+    memcpy(lv->h_mvps, h_mvps, (size_t)lv->S * 16 * sizeof(float));
+    for (int w = 0; w < lv->Wn; ++w) {
+        const double *m = h_forward + (size_t)w * 9;
+        const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+        if (det == 0.0) return NMI_ERR_INVALID_ARGUMENT;
+        const double inv[9] = {(m[4] * m[8] - m[5] * m[7]) / det, (m[2] * m[7] - m[1] * m[8]) / det, (m[1] * m[5] - m[2] * m[4]) / det,
+                               (m[5] * m[6] - m[3] * m[8]) / det, (m[0] * m[8] - m[2] * m[6]) / det, (m[2] * m[3] - m[0] * m[5]) / det,
+                               (m[3] * m[7] - m[4] * m[6]) / det, (m[1] * m[6] - m[0] * m[7]) / det, (m[0] * m[4] - m[1] * m[3]) / det};
+        for (int k = 0; k < 9; ++k) lv->h_coeffs[w * 9 + k] = (float)inv[k];
+    }
+    NMI_HIP_TRY(ctx, hipGraphLaunch(lv->exec, ctx->stream));
+    NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return nmi_key_unpack(*lv->h_key, h_best_index, h_best_score);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Streaming pipeline (config 5): double-buffered render stacks, copy stream beside the compute stream.
+// ---------------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+struct nmi_stream {
+    nmi_ctx *ctx = nullptr;
+    int depth = 0, max_S = 0, max_Wn = 0;
+    hipStream_t copy = nullptr;
+    struct Slot {
+        uint8_t *d_renders = nullptr;
+        unsigned long long *d_key = nullptr;
+        unsigned long long *h_key = nullptr;
+        hipEvent_t copied = nullptr, done = nullptr;
+        int64_t ticket = -1;
+        bool waited = true;
+    };
+    Slot *slots = nullptr;
+    uint8_t *d_frame[2] = {nullptr, nullptr};  // frames alternate so an upload never overwrites one still being warped
+    uint8_t *d_warps[2] = {nullptr, nullptr};
+    hipEvent_t frame_copied = nullptr, warps_free[2] = {nullptr, nullptr};
+    int warp_buf = 0;      // buffer holding the current warp stack
+    int cur_Wn = 0;
+    bool have_warps = false;
+    int64_t next_ticket = 0;
+};
+
+extern "C" {
+
+int nmi_stream_destroy(nmi_stream *st)
+{
+    if (!st) return NMI_OK;
+    DeviceGuard guard(st->ctx->device);
+    (void)hipStreamSynchronize(st->ctx->stream);
+    if (st->copy) (void)hipStreamSynchronize(st->copy);
+    for (int i = 0; st->slots && i < st->depth; ++i) {
+        nmi_stream::Slot &s = st->slots[i];
+        if (s.d_renders) (void)hipFree(s.d_renders);
+        if (s.d_key) (void)hipFree(s.d_key);
+        if (s.h_key) (void)hipHostFree(s.h_key);
+        if (s.copied) (void)hipEventDestroy(s.copied);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    delete[] st->slots;
+    for (int b = 0; b < 2; ++b) {
+        if (st->d_frame[b]) (void)hipFree(st->d_frame[b]);
+        if (st->d_warps[b]) (void)hipFree(st->d_warps[b]);
+        if (st->warps_free[b]) (void)hipEventDestroy(st->warps_free[b]);
+    }
+    if (st->frame_copied) (void)hipEventDestroy(st->frame_copied);
+    if (st->copy) (void)hipStreamDestroy(st->copy);
+    delete st;
+    return NMI_OK;
+}
+
+int nmi_stream_create(nmi_ctx *ctx, int32_t max_S, int32_t max_Wn, int32_t depth, nmi_stream **out)
+{
+    if (!ctx || !out || max_S <= 0 || max_Wn <= 0 || depth < 2 || depth > 64) return NMI_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    DeviceGuard guard(ctx->device);
+    nmi_stream *st = new (std::nothrow) nmi_stream;
+    if (!st) return NMI_ERR_INVALID_ARGUMENT;
+    st->ctx = ctx;
+    st->depth = depth;
+    st->max_S = max_S;
+    st->max_Wn = max_Wn;
+    st->slots = new (std::nothrow) nmi_stream::Slot[depth];
+    const size_t npix = (size_t)ctx->npix;
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t r) {
+        if (e == hipSuccess) e = r;
+        return r == hipSuccess;
+    };
+    ok(hipStreamCreateWithFlags(&st->copy, hipStreamNonBlocking));
+    for (int i = 0; st->slots && i < depth && e == hipSuccess; ++i) {
+        nmi_stream::Slot &s = st->slots[i];
+        ok(hipMalloc((void **)&s.d_renders, npix * max_S));
+        ok(hipMalloc((void **)&s.d_key, sizeof(unsigned long long)));
+        ok(hipHostMalloc((void **)&s.h_key, sizeof(unsigned long long), hipHostMallocDefault));
+        ok(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+        ok(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    }
+    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+        ok(hipMalloc((void **)&st->d_frame[b], npix));
+        ok(hipMalloc((void **)&st->d_warps[b], npix * max_Wn));
+        ok(hipEventCreateWithFlags(&st->warps_free[b], hipEventDisableTiming));
+    }
+    ok(hipEventCreateWithFlags(&st->frame_copied, hipEventDisableTiming));
+    if (!st->slots || e != hipSuccess) {
+        const int rc = st->slots ? hip_fail(ctx, e, "nmi_stream_create") : NMI_ERR_INVALID_ARGUMENT;
+        nmi_stream_destroy(st);
+        return rc;
+    }
+    *out = st;
+    return NMI_OK;
+}
+
+int nmi_stream_submit(nmi_stream *st, const uint8_t *h_render_stack, int32_t S, const uint8_t *h_frame,
+                      const double *h_forward, int32_t Wn, int64_t *ticket)
+{
+    if (!st || !h_render_stack || !ticket || S <= 0 || S > st->max_S) return NMI_ERR_INVALID_ARGUMENT;
+    if (h_frame && (!h_forward || Wn <= 0 || Wn > st->max_Wn)) return NMI_ERR_INVALID_ARGUMENT;
+    if (!h_frame && !st->have_warps) return NMI_ERR_INVALID_ARGUMENT;
+    nmi_ctx *ctx = st->ctx;
+    ctx->detail.clear();
+    DeviceGuard guard(ctx->device);
+    const int64_t t = st->next_ticket;
+    nmi_stream::Slot &s = st->slots[t % st->depth];
+    if (!s.waited) return NMI_ERR_NOT_READY;  // the ticket that used this slot has not been collected yet
+    const size_t npix = (size_t)ctx->npix;
+
+    // copy stream: render stack of this level into the slot (the slot's previous search finished: it was waited for)
+    NMI_HIP_TRY(ctx, hipMemcpyAsync(s.d_renders, h_render_stack, npix * S, hipMemcpyHostToDevice, st->copy));
+    if (h_frame) {
+        const int nb = st->have_warps ? st->warp_buf ^ 1 : 0;
+        // the buffer being refilled was last read by searches submitted before the previous frame switch
+        NMI_HIP_TRY(ctx, hipStreamWaitEvent(st->copy, st->warps_free[nb], 0));
+        NMI_HIP_TRY(ctx, hipMemcpyAsync(st->d_frame[nb], h_frame, npix, hipMemcpyHostToDevice, st->copy));
+        NMI_HIP_TRY(ctx, hipEventRecord(st->frame_copied, st->copy));
+        NMI_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, st->frame_copied, 0));
+        if (st->have_warps) NMI_HIP_TRY(ctx, hipEventRecord(st->warps_free[st->warp_buf], ctx->stream));
+        int rc = nmi_warp_stack(ctx, st->d_frame[nb], h_forward, Wn, st->d_warps[nb]);
+        if (rc != NMI_OK) return rc;
+        st->warp_buf = nb;
+        st->cur_Wn = Wn;
+        st->have_warps = true;
+    }
+    NMI_HIP_TRY(ctx, hipEventRecord(s.copied, st->copy));
+
+    // compute stream: search on the slot, winner to pinned host memory
+    NMI_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s.copied, 0));
+    int rc = enqueue_grid(ctx, s.d_renders, S, 0, S, st->d_warps[st->warp_buf], st->cur_Wn, nullptr, s.d_key, false, nullptr,
+                          nullptr, nullptr, nullptr);
+    if (rc != NMI_OK) return rc;
+    NMI_HIP_TRY(ctx, hipMemcpyAsync(s.h_key, s.d_key, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    NMI_HIP_TRY(ctx, hipEventRecord(s.done, ctx->stream));
+    s.ticket = t;
+    s.waited = false;
+    *ticket = t;
+    ++st->next_ticket;
+    return NMI_OK;
+}
+
+int nmi_stream_wait(nmi_stream *st, int64_t ticket, int64_t *h_best_index, float *h_best_score)
+{
+    if (!st || ticket < 0 || ticket >= st->next_ticket) return NMI_ERR_INVALID_ARGUMENT;
+    nmi_stream::Slot &s = st->slots[ticket % st->depth];
+    if (s.ticket != ticket || s.waited) return NMI_ERR_INVALID_ARGUMENT;  // overwritten or already collected
+    nmi_ctx *ctx = st->ctx;
+    DeviceGuard guard(ctx->device);
+    NMI_HIP_TRY(ctx, hipEventSynchronize(s.done));
+    s.waited = true;
+    return nmi_key_unpack(*s.h_key, h_best_index, h_best_score);
+}
+
+}  // extern "C"

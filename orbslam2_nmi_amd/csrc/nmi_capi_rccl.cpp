@@ -1,0 +1,116 @@
+// nmi_capi_rccl.cpp -- the RCCL entry points of include/nmi_hip.h.
+#include <dlfcn.h>
+
+#include "nmi_ctx.h"
+
+using namespace nmi_internal;
+
+// RCCL is resolved at run time (dlopen) so that single-GPU users never load librccl.
+namespace {
+struct NcclUniqueId128 {
+    char internal[128];
+};
+typedef int (*fn_get_unique_id)(NcclUniqueId128 *);
+typedef int (*fn_comm_init_rank)(void **, int, NcclUniqueId128, int);
+typedef int (*fn_comm_destroy)(void *);
+typedef int (*fn_all_reduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef const char *(*fn_error_string)(int);
+
+struct Rccl {
+    void *handle = nullptr;
+    fn_get_unique_id get_unique_id = nullptr;
+    fn_comm_init_rank comm_init_rank = nullptr;
+    fn_comm_destroy comm_destroy = nullptr;
+    fn_all_reduce all_reduce = nullptr;
+    fn_error_string error_string = nullptr;
+    bool ok = false;
+};
+
+// ncclDataType_t / ncclRedOp_t values of rccl.h (ncclUint64 = 5, ncclMax = 2).
+constexpr int kNcclUint64 = 5;
+constexpr int kNcclMax = 2;
+
+Rccl &rccl()
+{
+    static Rccl r = [] {
+        Rccl x;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names)
+            if ((x.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!x.handle) return x;
+        x.get_unique_id = (fn_get_unique_id)dlsym(x.handle, "ncclGetUniqueId");
+        x.comm_init_rank = (fn_comm_init_rank)dlsym(x.handle, "ncclCommInitRank");
+        x.comm_destroy = (fn_comm_destroy)dlsym(x.handle, "ncclCommDestroy");
+        x.all_reduce = (fn_all_reduce)dlsym(x.handle, "ncclAllReduce");
+        x.error_string = (fn_error_string)dlsym(x.handle, "ncclGetErrorString");
+        x.ok = x.get_unique_id && x.comm_init_rank && x.comm_destroy && x.all_reduce;
+        return x;
+    }();
+    return r;
+}
+
+int rccl_fail(nmi_ctx *ctx, int r, const char *what)
+{
+    if (ctx) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "%s: %s (%d)", what, rccl().error_string ? rccl().error_string(r) : "rccl", r);
+        ctx->detail = buf;
+    }
+    return NMI_ERR_RCCL - r;
+}
+}  // namespace
+
+extern "C" {
+
+int nmi_rccl_unique_id(uint8_t out_id[128])
+{
+    if (!out_id) return NMI_ERR_INVALID_ARGUMENT;
+    if (!rccl().ok) return NMI_ERR_UNSUPPORTED;
+    NcclUniqueId128 id;
+    int r = rccl().get_unique_id(&id);
+    if (r != 0) return rccl_fail(nullptr, r, "ncclGetUniqueId");
+    memcpy(out_id, id.internal, 128);
+    return NMI_OK;
+}
+
+int nmi_rccl_comm_init(nmi_ctx *ctx, const uint8_t id[128], int32_t rank, int32_t nranks, void **out_comm)
+{
+    if (!ctx || !id || !out_comm || nranks <= 0 || rank < 0 || rank >= nranks) return NMI_ERR_INVALID_ARGUMENT;
+    if (!rccl().ok) return NMI_ERR_UNSUPPORTED;
+    DeviceGuard guard(ctx->device);
+    NcclUniqueId128 uid;
+    memcpy(uid.internal, id, 128);
+    void *comm = nullptr;
+    int r = rccl().comm_init_rank(&comm, nranks, uid, rank);
+    if (r != 0) return rccl_fail(ctx, r, "ncclCommInitRank");
+    *out_comm = comm;
+    return NMI_OK;
+}
+
+int nmi_rccl_comm_destroy(void *nccl_comm)
+{
+    if (!nccl_comm) return NMI_OK;
+    if (!rccl().ok) return NMI_ERR_UNSUPPORTED;
+    int r = rccl().comm_destroy(nccl_comm);
+    return r == 0 ? NMI_OK : NMI_ERR_RCCL - r;
+}
+
+int nmi_search_grid_rccl(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S_local, int32_t s_offset, int32_t S_total,
+                         const uint8_t *warp_stack, int32_t Wn, float *d_ratings, void *nccl_comm, int64_t *h_best_index,
+                         float *h_best_score)
+{
+    if (!nccl_comm) return NMI_ERR_INVALID_ARGUMENT;
+    if (!rccl().ok) return NMI_ERR_UNSUPPORTED;
+    int rc = nmi_search_grid_shard(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn, d_ratings, nullptr, nullptr);
+    if (rc != NMI_OK) return rc;
+    DeviceGuard guard(ctx->device);
+    // The only exchange of the search: 8 bytes per rank, max over ranks.
+    unsigned long long *k = ctx->d_keys + ctx->last_slot;
+    int r = rccl().all_reduce(k, k, 1, kNcclUint64, kNcclMax, nccl_comm, ctx->stream);
+    if (r != 0) return rccl_fail(ctx, r, "ncclAllReduce");
+    NMI_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_key, k, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return nmi_key_unpack(*ctx->h_key, h_best_index, h_best_score);
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+// nmi_ctx.h -- internal: the context object behind include/nmi_hip.h and the helpers its translation units share
+// (nmi_capi.cpp: context + search; nmi_capi_producers.cpp: warp / render producers; nmi_capi_pipeline.cpp: captured level
+// and streaming pipeline; nmi_capi_rccl.cpp: the RCCL entry points).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "nmi_hip.h"
+#include "nmi_kernels.h"
+
+// Small host->device parameter uploads (warp coefficients, view matrices) go through a ring of pinned staging buffers so
+// that back-to-back submissions never have to wait for the stream: entry i is reused only after the copy that read it.
+struct StagingRing {
+    static constexpr int kSlots = 4;
+    float *h[kSlots] = {};
+    float *d[kSlots] = {};
+    hipEvent_t ev[kSlots] = {};
+    size_t cap = 0;  // floats per slot
+    unsigned uses = 0;
+};
+
+struct nmi_ctx {
+    nmi_params params{};
+    int device = 0;
+    int compute_units = 0;
+    int npix = 0;
+    int shift = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    float *table = nullptr;             // [npix + 1]
+    float *ratings = nullptr;           // internal rating table
+    int64_t ratings_cap = 0;
+    unsigned long long *d_keys = nullptr;  // two device slots for the packed winner, used alternately (ping-pong)
+    unsigned long long *h_key = nullptr;   // pinned host mirror (copy path)
+    unsigned int *d_done = nullptr;        // finished-workgroup counter
+    nmi::Mailbox *mailbox = nullptr;       // pinned, fine-grained: the kernel posts the winner here
+    unsigned int seq = 0;                  // launches that post to the mailbox so far (blocking calls only)
+    int slot = 0;                          // key slot of the next launch
+    int last_slot = 0;                     // key slot of the most recent launch
+    int result_path = 1;                   // 1 mailbox spin (default), 0 hipMemcpyAsync + stream sync
+    bool posted = false;                   // the most recent launch posts to the mailbox
+    float *d_pair_rating = nullptr;
+    int *d_order = nullptr;               // visiting order of the candidates (XCD-aware tiling), cached per grid shape
+    int *h_order = nullptr;
+    int64_t order_cap = 0;
+    int order_S = -1, order_Wn = -1;
+    int xcd_tiling = 1;                   // NMI_OPT_XCD_TILING
+    uint32_t *d_zbuf = nullptr;           // depth|colour anchor buffers of the point-cloud renderer (padded, per view)
+    int64_t zbuf_cap = 0;
+    StagingRing mvp_ring;
+    uint32_t *d_scratch = nullptr;        // drained-counter slabs of the pipelined kernel
+    int scratch_workgroups = 0;
+    // inverse homographies for the warp producer: a small ring of (pinned staging, device copy, "copy consumed" event)
+    // so that back-to-back submissions never wait for the stream
+    static constexpr int kWarpRing = 4;
+    float *d_warp_coeffs[kWarpRing] = {};
+    float *h_warp_coeffs[kWarpRing] = {};
+    hipEvent_t warp_ev[kWarpRing] = {};
+    int warp_coeffs_cap = 0;
+    unsigned warp_uses = 0;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    int hist_variant = 3;
+    int phase_mask = 3;
+    int workgroups = 0;
+    bool profiling = false;
+    bool have_timing = false;
+    std::string detail;
+};
+
+namespace nmi_internal {
+
+int hip_fail(nmi_ctx *ctx, hipError_t e, const char *what);
+int ensure_ratings(nmi_ctx *ctx, int64_t n);
+void build_order(int S, int Wn, int *order);
+int ensure_order(nmi_ctx *ctx, int S, int Wn);
+int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_offset, int S_total, const uint8_t *warp_stack, int Wn,
+                 float *d_ratings, unsigned long long *out_key, bool post, uint32_t *dbg_joint, uint32_t *dbg_h1, uint32_t *dbg_h2,
+                 float *dbg_sums);
+int stage_floats(nmi_ctx *ctx, StagingRing &ring, const float *h_src, size_t n, float **d_out);
+int fetch_key(nmi_ctx *ctx, unsigned long long *key);
+int check_grid_args(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_offset, int S_total, const uint8_t *warp_stack,
+                    int Wn);
+
+#define NMI_HIP_TRY(ctx, call)                                  \
+    do {                                                        \
+        hipError_t e_ = (call);                                 \
+        if (e_ != hipSuccess) return nmi_internal::hip_fail((ctx), e_, #call); \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool active = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) active = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (active) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace nmi_internal

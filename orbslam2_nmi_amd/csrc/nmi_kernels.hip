@@ -936,366 +936,4 @@ hipError_t launch_grid(const GridArgs &a, int workgroups, bool use_bg, hipStream
 int grid_kernel_lds_bytes() { return (int)sizeof(Lds); }
 size_t grid_kernel_scratch_bytes(int workgroups) { return (size_t)workgroups * 2 * kWords * sizeof(uint32_t); }
 
-// ---------------------------------------------------------------------------------------------------------
-// Warp-stack producer: Image::calculateWarping, Thirdparty/Localization/image.cpp:115-128 --
-// Wn calls of cv::cuda::warpPerspective(frame, warped[w], K*R*K^-1, size) with the defaults INTER_LINEAR,
-// BORDER_CONSTANT(0), forward matrix.  OpenCV 3.4.0 is not vendored in the reference and absent here, so the
-// arithmetic below follows OpenCV's published device path (inverse matrix as 9 floats; coeff = 1/(c6*x+c7*y+c8),
-// source coordinate coeff*(c0*x+c1*y+c2) in fp32; bilinear LinearFilter with floor(), the four taps accumulated in the
-// order (y1,x1) (y1,x2) (y2,x1) (y2,x2); saturate_cast<uchar> = round to nearest even) -- parity unpinned.
-// One thread produces 4 horizontally adjacent pixels of one warp and stores them as one dword.
-__device__ __forceinline__ float warp_tap(const uint8_t *__restrict__ src, int w, int h, int x, int y)
-{
-    return (x >= 0 && x < w && y >= 0 && y < h) ? (float)src[y * w + x] : 0.0f;  // BORDER_CONSTANT, value 0
-}
-
-__global__ __launch_bounds__(256) void nmi_warp_kernel(const uint8_t *__restrict__ frame, const float *__restrict__ coeffs,
-                                                       uint8_t *__restrict__ out, int width, int height, int quads_per_row)
-{
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    const int wi = blockIdx.z;
-    if (q >= quads_per_row) return;
-    const float *c = coeffs + wi * 9;
-    uint32_t packed = 0;
-    uint8_t px[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int x = q * 4 + k;
-        uint32_t v = 0;
-        if (x < width) {
-            const float fx = (float)x, fy = (float)y;
-            // OpenCV's device transform: one reciprocal of the homogeneous coordinate, two multiplies
-            const float coeff = 1.0f / (c[6] * fx + c[7] * fy + c[8]);
-            const float xs = coeff * (c[0] * fx + c[1] * fy + c[2]);
-            const float ys = coeff * (c[3] * fx + c[4] * fy + c[5]);
-            // coordinates far outside the frame (or non-finite) see only the constant border
-            float acc = 0.0f;
-            if (xs > -2.0f && xs < (float)(width + 1) && ys > -2.0f && ys < (float)(height + 1)) {
-                const int x1 = (int)floorf(xs), y1 = (int)floorf(ys);
-                const int x2 = x1 + 1, y2 = y1 + 1;
-                float t11, t21, t12, t22;
-                if (x1 >= 0 && x2 < width && y1 >= 0 && y2 < height) {  // all four taps inside: no per-tap border test
-                    const uint8_t *p = frame + y1 * width + x1;
-                    t11 = (float)p[0], t21 = (float)p[1], t12 = (float)p[width], t22 = (float)p[width + 1];
-                } else {
-                    t11 = warp_tap(frame, width, height, x1, y1), t21 = warp_tap(frame, width, height, x2, y1);
-                    t12 = warp_tap(frame, width, height, x1, y2), t22 = warp_tap(frame, width, height, x2, y2);
-                }
-                acc = acc + t11 * (((float)x2 - xs) * ((float)y2 - ys));
-                acc = acc + t21 * ((xs - (float)x1) * ((float)y2 - ys));
-                acc = acc + t12 * (((float)x2 - xs) * (ys - (float)y1));
-                acc = acc + t22 * ((xs - (float)x1) * (ys - (float)y1));
-            }
-            const float r = rintf(acc);
-            v = r <= 0.0f ? 0u : (r >= 255.0f ? 255u : (uint32_t)r);
-        }
-        px[k] = (uint8_t)v;
-        packed |= v << (8 * k);
-    }
-    uint8_t *dst = out + ((size_t)wi * height + y) * width + q * 4;
-    if ((width & 3) == 0 && ((uintptr_t)out & 3) == 0) {
-        *reinterpret_cast<uint32_t *>(dst) = packed;
-    } else {
-        for (int k = 0; k < 4 && q * 4 + k < width; ++k) dst[k] = px[k];
-    }
-}
-
-hipError_t launch_warp(const uint8_t *frame, const float *coeffs, uint8_t *out, int width, int height, int Wn,
-                       hipStream_t stream)
-{
-    const int quads = (width + 3) / 4;
-    dim3 block(256), grid((quads + 255) / 256, height, Wn);
-    hipLaunchKernelGGL(nmi_warp_kernel, grid, block, 0, stream, frame, coeffs, out, width, height, quads);
-    return hipGetLastError();
-}
-
-
-// ---------------------------------------------------------------------------------------------------------
-// Render-stack producer for coloured point clouds: Rendering<4>::renderToTextureOnGPU,
-// Thirdparty/Localization/rendering.hpp:530-630 with shaders/ShadingWithColor.{vertex,fragment}shader --
-// glClearColor(1,1,1) (:533), gl_Position = MVP * vec4(p,1), GL_POINTS of glPointSize(PointSize) (:307), GL_DEPTH_TEST
-// with GL_LESS (:294-297), colour = vertex colour, only the red channel kept (GL_RED texture, :347).
-// The OpenGL rasteriser is not part of the reference tree; the rules below are the OpenGL 3.3 specification's for
-// non-antialiased points (centre clipped against the view volume; size rounded to an integer >= 1; odd sizes centred on
-// floor(x)+0.5, even sizes on floor(x+0.5); 24-bit depth) evaluated in fp32 -- parity with a GL driver is unpinned.
-// Depth test + colour write are one 32-bit atomicMin on (depth24 << 8 | red8); equal depths resolve to the darker
-// fragment (GL: the first drawn).  Rows are written bottom-up like a GL texture (what NMI.cu:82 flips back).
-__global__ __launch_bounds__(256) void nmi_zbuf_clear_kernel(uint32_t *zbuf, size_t n)
-{
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) zbuf[i] = 0xFFFFFFFFu;
-}
-
-// One lane per point, looping over the S views: the cloud is read once, not once per view (27 views of a 3 M-point
-// cloud would otherwise stream 1.3 GB per level); the S matrices sit in LDS.
-constexpr int kMaxViewsPerLaunch = 64;
-
-__global__ __launch_bounds__(256) void nmi_splat_kernel(const float *__restrict__ xyz, const float *__restrict__ red, long long npoints,
-                                                        const float *__restrict__ mvps, int views, uint32_t *__restrict__ zbuf,
-                                                        int width, int height, int size)
-{
-    __shared__ float m_all[kMaxViewsPerLaunch * 16];
-    for (int t = threadIdx.x; t < views * 16; t += blockDim.x) m_all[t] = mvps[t];  // column-major like glm: m[c*4 + r]
-    __syncthreads();
-    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (i >= npoints) return;
-    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-    const float r = red[i];
-    const uint32_t colour = (uint32_t)(fminf(fmaxf(r, 0.0f), 1.0f) * 255.0f + 0.5f);
-    for (int s = 0; s < views; ++s) {
-        const float *m = m_all + s * 16;
-        // glm mat4 * vec4: (m0*x + m1*y) + (m2*z + m3*1), component-wise
-        const float cx = (m[0] * x + m[4] * y) + (m[8] * z + m[12]);
-        const float cy = (m[1] * x + m[5] * y) + (m[9] * z + m[13]);
-        const float cz = (m[2] * x + m[6] * y) + (m[10] * z + m[14]);
-        const float cw = (m[3] * x + m[7] * y) + (m[11] * z + m[15]);
-        if (!(cw > 0.0f) || cx < -cw || cx > cw || cy < -cw || cy > cw || cz < -cw || cz > cw) continue;  // point clipping
-        const float xw = (cx / cw * 0.5f + 0.5f) * (float)width;
-        const float yw = (cy / cw * 0.5f + 0.5f) * (float)height;
-        const float zw = cz / cw * 0.5f + 0.5f;
-        const uint32_t depth = (uint32_t)(zw * 16777215.0f + 0.5f);
-        const uint32_t frag = (depth << 8) | colour;
-        int x0, y0;
-        if (size & 1) {
-            x0 = (int)floorf(xw) - (size - 1) / 2;
-            y0 = (int)floorf(yw) - (size - 1) / 2;
-        } else {
-            x0 = (int)floorf(xw + 0.5f) - size / 2;
-            y0 = (int)floorf(yw + 0.5f) - size / 2;
-        }
-        // Only the sprite's anchor (its lowest-left pixel) is written here: one atomic per point and view instead of
-        // size^2.  Two points with the same anchor have the same footprint, so the farther one would lose on every
-        // pixel anyway; the resolve pass below takes, for each pixel, the minimum over the size^2 anchors whose
-        // sprites cover it -- exactly the depth-tested sprites.  The buffer is padded by size-1 so that sprites
-        // straddling the left / bottom edge keep their anchor.
-        const int ax = x0 + size - 1, ay = y0 + size - 1, wp = width + size - 1, hp = height + size - 1;
-        if (ax < 0 || ax >= wp || ay < 0 || ay >= hp) continue;
-        atomicMin(&zbuf[(size_t)s * wp * hp + (size_t)ay * wp + ax], frag);
-    }
-}
-
-// Four horizontally adjacent output pixels per lane: the size x (size+3) anchor window is read once and the four
-// results leave as one dword.
-__global__ __launch_bounds__(256) void nmi_zbuf_resolve_kernel(const uint32_t *__restrict__ zbuf, uint8_t *__restrict__ out, int views,
-                                                               int width, int height, int size)
-{
-    const int wp = width + size - 1, hp = height + size - 1;
-    const int quads = (width + 3) / 4;
-    const size_t n = (size_t)views * height * quads;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int q = (int)(i % quads), py = (int)((i / quads) % height), s = (int)(i / ((size_t)quads * height));
-        const int px = q * 4;
-        const uint32_t *base = zbuf + (size_t)s * wp * hp + (size_t)py * wp + px;
-        uint32_t best[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        for (int dy = 0; dy < size; ++dy) {
-            const uint32_t *row = base + (size_t)dy * wp;
-            for (int dx = 0; dx < size + 3; ++dx) {
-                if (px + dx >= wp) break;
-                const uint32_t v = row[dx];
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (dx >= k && dx - k < size) best[k] = min(best[k], v);
-            }
-        }
-        uint8_t *dst = out + ((size_t)s * height + py) * width + px;
-        if (px + 3 < width && (width & 3) == 0) {
-            *reinterpret_cast<uint32_t *>(dst) = (best[0] & 0xFFu) | ((best[1] & 0xFFu) << 8) | ((best[2] & 0xFFu) << 16) | (best[3] << 24);
-        } else {
-            for (int k = 0; k < 4 && px + k < width; ++k) dst[k] = (uint8_t)(best[k] & 0xFFu);  // untouched pixels keep 255
-        }
-    }
-}
-
-size_t render_zbuf_words(int S, int width, int height, int size) { return (size_t)S * (width + size - 1) * (height + size - 1); }
-
-// ---------------------------------------------------------------------------------------------------------
-// Render-stack producer for textured meshes (nmi_prop_RENDER 1): Rendering<1>::renderToTextureOnGPU,
-// rendering.hpp:530-630 with shaders/ShadingWithTexture.* -- glDrawArrays(GL_TRIANGLES) of the OBJ's expanded
-// vertex / uv arrays (objloader.cpp:140-224), GL_CULL_FACE (back faces, counter-clockwise front; rendering.hpp:300),
-// depth test GL_LESS, fragment colour = 0.299 r + 0.587 g + 0.114 b of the texture sample (fragment shader :16) with
-// GL_REPEAT wrap, GL_LINEAR magnification and GL_LINEAR_MIPMAP_LINEAR minification (texture.cpp:88-92).
-// What follows is the OpenGL 3.3 pipeline in fp32 as the specification words it (pixel centres at +0.5, top-left
-// fill rule, perspective-correct interpolation, isotropic level of detail from the per-pixel uv derivatives); a real
-// driver rasterises in fixed point and is free in its LOD approximation, so parity with one is unpinned.
-// Simplification: a triangle with a vertex at w <= 0 (behind the eye plane) is dropped instead of clipped.
-// The texture arrives as per-level fp32 luma (host: nmi_texture_create), since every filter here is linear.
-struct MeshTexture {
-    const float *luma;   // all levels, level l at luma + off[l], row-major, row 0 = v 0
-    int levels;
-    int w[16], h[16];
-    long long off[16];
-};
-
-__device__ __forceinline__ float tex_bilinear(const MeshTexture &t, int l, float u, float v)
-{
-    const int w = t.w[l], h = t.h[l];
-    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
-    const float xf = floorf(x), yf = floorf(y);
-    const float fx = x - xf, fy = y - yf;
-    int i0 = (int)xf % w, j0 = (int)yf % h;  // GL_REPEAT
-    if (i0 < 0) i0 += w;
-    if (j0 < 0) j0 += h;
-    const int i1 = i0 + 1 == w ? 0 : i0 + 1, j1 = j0 + 1 == h ? 0 : j0 + 1;
-    const float *p = t.luma + t.off[l];
-    const float t00 = p[(size_t)j0 * w + i0], t10 = p[(size_t)j0 * w + i1], t01 = p[(size_t)j1 * w + i0], t11 = p[(size_t)j1 * w + i1];
-    const float a = t00 + (t10 - t00) * fx, b = t01 + (t11 - t01) * fx;
-    return a + (b - a) * fy;
-}
-
-__device__ __forceinline__ bool edge_owner(float ex, float ey)
-{
-    // top-left rule for a counter-clockwise triangle in y-up window coordinates: an edge owns the pixels exactly on it
-    // when it is a left edge (going down) or a top edge (horizontal, going left)
-    return ey < 0.0f || (ey == 0.0f && ex < 0.0f);
-}
-
-__global__ __launch_bounds__(256) void nmi_mesh_kernel(const float *__restrict__ xyz, const float *__restrict__ uv, long long ntri,
-                                                       const float *__restrict__ mvps, int views, uint32_t *__restrict__ zbuf,
-                                                       int width, int height, MeshTexture tex)
-{
-    __shared__ float m_all[kMaxViewsPerLaunch * 16];
-    for (int t = threadIdx.x; t < views * 16; t += blockDim.x) m_all[t] = mvps[t];
-    __syncthreads();
-    const long long tri = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (tri >= ntri) return;
-    float px[3], py[3], pz[3], tu[3], tv[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        px[k] = xyz[(tri * 3 + k) * 3], py[k] = xyz[(tri * 3 + k) * 3 + 1], pz[k] = xyz[(tri * 3 + k) * 3 + 2];
-        tu[k] = uv[(tri * 3 + k) * 2], tv[k] = uv[(tri * 3 + k) * 2 + 1];
-    }
-    const float tw = (float)tex.w[0], th = (float)tex.h[0];
-    for (int s = 0; s < views; ++s) {
-        const float *m = m_all + s * 16;
-        float cx[3], cy[3], cz[3], cw[3];
-        bool behind = false;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            cx[k] = (m[0] * px[k] + m[4] * py[k]) + (m[8] * pz[k] + m[12]);
-            cy[k] = (m[1] * px[k] + m[5] * py[k]) + (m[9] * pz[k] + m[13]);
-            cz[k] = (m[2] * px[k] + m[6] * py[k]) + (m[10] * pz[k] + m[14]);
-            cw[k] = (m[3] * px[k] + m[7] * py[k]) + (m[11] * pz[k] + m[15]);
-            behind = behind || !(cw[k] > 0.0f);
-        }
-        if (behind) continue;
-        if ((cx[0] < -cw[0] && cx[1] < -cw[1] && cx[2] < -cw[2]) || (cx[0] > cw[0] && cx[1] > cw[1] && cx[2] > cw[2]) ||
-            (cy[0] < -cw[0] && cy[1] < -cw[1] && cy[2] < -cw[2]) || (cy[0] > cw[0] && cy[1] > cw[1] && cy[2] > cw[2]) ||
-            (cz[0] < -cw[0] && cz[1] < -cw[1] && cz[2] < -cw[2]) || (cz[0] > cw[0] && cz[1] > cw[1] && cz[2] > cw[2]))
-            continue;
-        float xw[3], yw[3], zw[3], iw[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            xw[k] = (cx[k] / cw[k] * 0.5f + 0.5f) * (float)width;
-            yw[k] = (cy[k] / cw[k] * 0.5f + 0.5f) * (float)height;
-            zw[k] = cz[k] / cw[k] * 0.5f + 0.5f;
-            iw[k] = 1.0f / cw[k];
-        }
-        const float area = (xw[1] - xw[0]) * (yw[2] - yw[0]) - (xw[2] - xw[0]) * (yw[1] - yw[0]);
-        if (!(area > 0.0f)) continue;  // back face (or degenerate): GL_CULL_FACE, front = counter-clockwise
-        const float minx = fminf(xw[0], fminf(xw[1], xw[2])), maxx = fmaxf(xw[0], fmaxf(xw[1], xw[2]));
-        const float miny = fminf(yw[0], fminf(yw[1], yw[2])), maxy = fmaxf(yw[0], fmaxf(yw[1], yw[2]));
-        const int x_lo = max(0, (int)ceilf(minx - 0.5f)), x_hi = min(width - 1, (int)floorf(maxx - 0.5f));
-        const int y_lo = max(0, (int)ceilf(miny - 0.5f)), y_hi = min(height - 1, (int)floorf(maxy - 0.5f));
-        if (x_lo > x_hi || y_lo > y_hi) continue;
-        // edge k is opposite vertex k: from vertex (k+1)%3 to vertex (k+2)%3
-        float ex[3], ey[3];
-        bool own[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int a = (k + 1) % 3, b = (k + 2) % 3;
-            ex[k] = xw[b] - xw[a];
-            ey[k] = yw[b] - yw[a];
-            own[k] = edge_owner(ex[k], ey[k]);
-        }
-        const float inv_area = 1.0f / area;
-        uint32_t *img = zbuf + (size_t)s * width * height;
-        auto attributes = [&](float fxp, float fyp, float &u, float &v, float &z, float (&bary)[3]) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int a = (k + 1) % 3;
-                bary[k] = (ex[k] * (fyp - yw[a]) - ey[k] * (fxp - xw[a])) * inv_area;
-            }
-            z = bary[0] * zw[0] + bary[1] * zw[1] + bary[2] * zw[2];
-            const float q = bary[0] * iw[0] + bary[1] * iw[1] + bary[2] * iw[2];
-            u = (bary[0] * tu[0] * iw[0] + bary[1] * tu[1] * iw[1] + bary[2] * tu[2] * iw[2]) / q;
-            v = (bary[0] * tv[0] * iw[0] + bary[1] * tv[1] * iw[1] + bary[2] * tv[2] * iw[2]) / q;
-        };
-        for (int yy = y_lo; yy <= y_hi; ++yy) {
-            for (int xx = x_lo; xx <= x_hi; ++xx) {
-                const float fxp = (float)xx + 0.5f, fyp = (float)yy + 0.5f;
-                float bary[3], u, v, z;
-                attributes(fxp, fyp, u, v, z, bary);
-                bool inside = true;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) inside = inside && (bary[k] > 0.0f || (bary[k] == 0.0f && own[k]));
-                if (!inside) continue;
-                if (!(z >= 0.0f && z <= 1.0f)) continue;  // depth clipping
-                float b2[3], ux, vx, uy, vy, zz;
-                attributes(fxp + 1.0f, fyp, ux, vx, zz, b2);
-                attributes(fxp, fyp + 1.0f, uy, vy, zz, b2);
-                const float dudx = (ux - u) * tw, dvdx = (vx - v) * th, dudy = (uy - u) * tw, dvdy = (vy - v) * th;
-                const float rho = fmaxf(sqrtf(dudx * dudx + dvdx * dvdx), sqrtf(dudy * dudy + dvdy * dvdy));
-                float luma;
-                const float lambda = log2f(rho);
-                if (!(lambda > 0.0f)) {
-                    luma = tex_bilinear(tex, 0, u, v);  // magnification: GL_LINEAR on the base level
-                } else {
-                    const float lc = fminf(lambda, (float)(tex.levels - 1));
-                    const int l0 = (int)floorf(lc), l1 = min(l0 + 1, tex.levels - 1);
-                    const float f = lc - (float)l0;
-                    const float s0 = tex_bilinear(tex, l0, u, v), s1 = tex_bilinear(tex, l1, u, v);
-                    luma = s0 + (s1 - s0) * f;   // GL_LINEAR_MIPMAP_LINEAR
-                }
-                const uint32_t colour = (uint32_t)(fminf(fmaxf(luma, 0.0f), 1.0f) * 255.0f + 0.5f);
-                const uint32_t depth = (uint32_t)(z * 16777215.0f + 0.5f);
-                atomicMin(&img[(size_t)yy * width + xx], (depth << 8) | colour);
-            }
-        }
-    }
-}
-
-hipError_t launch_render_mesh(const float *xyz, const float *uv, long long ntri, const float *luma, int levels, const int *lw,
-                              const int *lh, const long long *loff, const float *mvps, int S, uint32_t *zbuf, uint8_t *out,
-                              int width, int height, hipStream_t stream)
-{
-    MeshTexture tex{};
-    tex.luma = luma;
-    tex.levels = levels;
-    for (int l = 0; l < levels && l < 16; ++l) tex.w[l] = lw[l], tex.h[l] = lh[l], tex.off[l] = loff[l];
-    const size_t nz = (size_t)S * width * height;
-    hipLaunchKernelGGL(nmi_zbuf_clear_kernel, dim3((unsigned)((nz + 255) / 256 < 4096 ? (nz + 255) / 256 : 4096)), dim3(256), 0, stream, zbuf, nz);
-    if (ntri > 0) {
-        for (int s0 = 0; s0 < S; s0 += kMaxViewsPerLaunch) {
-            const int views = S - s0 < kMaxViewsPerLaunch ? S - s0 : kMaxViewsPerLaunch;
-            hipLaunchKernelGGL(nmi_mesh_kernel, dim3((unsigned)((ntri + 255) / 256)), dim3(256), 0, stream, xyz, uv, ntri,
-                               mvps + (size_t)s0 * 16, views, zbuf + (size_t)s0 * width * height, width, height, tex);
-        }
-    }
-    const size_t nq = (size_t)S * height * ((width + 3) / 4);
-    hipLaunchKernelGGL(nmi_zbuf_resolve_kernel, dim3((unsigned)((nq + 255) / 256 < 8192 ? (nq + 255) / 256 : 8192)), dim3(256), 0, stream, zbuf,
-                       out, S, width, height, 1);
-    return hipGetLastError();
-}
-
-hipError_t launch_render_points(const float *xyz, const float *red, long long npoints, const float *mvps, int S, uint32_t *zbuf,
-                                uint8_t *out, int width, int height, int size, hipStream_t stream)
-{
-    const size_t nz = render_zbuf_words(S, width, height, size);
-    const size_t n = (size_t)S * width * height;
-    hipLaunchKernelGGL(nmi_zbuf_clear_kernel, dim3((unsigned)((nz + 255) / 256 < 4096 ? (nz + 255) / 256 : 4096)), dim3(256), 0, stream, zbuf, nz);
-    if (npoints > 0) {
-        const size_t per_view = (size_t)(width + size - 1) * (height + size - 1);
-        for (int s0 = 0; s0 < S; s0 += kMaxViewsPerLaunch) {
-            const int views = S - s0 < kMaxViewsPerLaunch ? S - s0 : kMaxViewsPerLaunch;
-            hipLaunchKernelGGL(nmi_splat_kernel, dim3((unsigned)((npoints + 255) / 256)), dim3(256), 0, stream, xyz, red, npoints,
-                               mvps + (size_t)s0 * 16, views, zbuf + (size_t)s0 * per_view, width, height, size);
-        }
-    }
-    const size_t nq = (size_t)S * height * ((width + 3) / 4);
-    hipLaunchKernelGGL(nmi_zbuf_resolve_kernel, dim3((unsigned)((nq + 255) / 256 < 8192 ? (nq + 255) / 256 : 8192)), dim3(256), 0, stream, zbuf,
-                       out, S, width, height, size);
-    (void)n;
-    return hipGetLastError();
-}
-
 }  // namespace nmi
