@@ -80,15 +80,9 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     a.Wn = Wn;
     a.s_offset = s_offset;
     a.S_total = S_total;
-    a.width = p.width;
-    a.height = p.height;
-    a.npix = ctx->npix;
-    a.vec_ok = (p.width % 16 == 0) && (((uintptr_t)render_stack | (uintptr_t)warp_stack) % 16 == 0);
-    a.chunks_per_row = a.vec_ok ? p.width / 16 : 1;
-    a.cpr_magic = a.chunks_per_row > 1 ? (uint32_t)((0x100000000ull + a.chunks_per_row - 1) / a.chunks_per_row) : 0u;
+    nmi::set_geometry(a, p.width, p.height, render_stack, warp_stack, p.render_bottom_up != 0);
     a.shift = ctx->shift;
     a.mode = p.mode;
-    a.flip = p.render_bottom_up ? 1 : 0;
     a.table = ctx->table;
     a.scratch = ctx->d_scratch;
     a.order = nullptr;

@@ -101,15 +101,9 @@ int nmi_level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int64
     a.Wn = Wn;
     a.s_offset = 0;
     a.S_total = S;
-    a.width = p.width;
-    a.height = p.height;
-    a.npix = ctx->npix;
-    a.vec_ok = (p.width % 16 == 0) && (((uintptr_t)lv->d_renders | (uintptr_t)lv->d_warps) % 16 == 0);
-    a.chunks_per_row = a.vec_ok ? p.width / 16 : 1;
-    a.cpr_magic = a.chunks_per_row > 1 ? (uint32_t)((0x100000000ull + a.chunks_per_row - 1) / a.chunks_per_row) : 0u;
+    nmi::set_geometry(a, p.width, p.height, lv->d_renders, lv->d_warps, p.render_bottom_up != 0);
     a.shift = ctx->shift;
     a.mode = p.mode;
-    a.flip = p.render_bottom_up ? 1 : 0;
     a.table = ctx->table;
     a.order = lv->d_order;
     a.key = lv->d_key;        // reset by a memset node before every replay (the ping-pong of plain launches needs

@@ -24,7 +24,10 @@ struct GridArgs {
     int width, height, npix;
     int chunks_per_row;           // width / 16 when vec_ok
     uint32_t cpr_magic;           // ceil(2^32 / chunks_per_row)
-    int vec_ok;                   // width % 16 == 0 and both stacks 16-byte aligned
+    int vec_ok;                   // width % 16 == 0, width >= 32 and both stacks 16-byte aligned
+    // 16-byte chunk c of the frame (row y = c / chunks_per_row) meets render chunk c + flip_base + y * flip_row:
+    // (0, 0) for a top-down render, ((H - 1) * cpr, -2 * cpr) for a bottom-up one (NMI.cu:82)
+    int flip_base, flip_row;
     int shift;                    // intensity >> shift (bins = 256 >> shift)
     int mode;                     // NMI_MODE_*_
     int flip;                     // render stored bottom-up (NMI.cu:82)
@@ -43,6 +46,20 @@ struct GridArgs {
     int hist_variant;             // 0 per-pixel wrap test, 1 batched, 2 unchecked (ablation), 3 optimistic + verify (default), 4 pipelined (experimental)
     int phase_mask;               // bit 0 histogram phase, bit 1 decode + score (ablation; product uses 3)
 };
+
+// Image geometry of a launch (shared by the search and the level-graph entry points).
+inline void set_geometry(GridArgs &a, int width, int height, const void *render_stack, const void *warp_stack, bool render_bottom_up)
+{
+    a.width = width;
+    a.height = height;
+    a.npix = width * height;
+    a.vec_ok = (width % 16 == 0) && width >= 32 && (((uintptr_t)render_stack | (uintptr_t)warp_stack) % 16 == 0);
+    a.chunks_per_row = a.vec_ok ? width / 16 : 1;
+    a.cpr_magic = a.chunks_per_row > 1 ? (uint32_t)((0x100000000ull + a.chunks_per_row - 1) / a.chunks_per_row) : 0u;
+    a.flip = render_bottom_up ? 1 : 0;
+    a.flip_base = render_bottom_up ? (height - 1) * a.chunks_per_row : 0;
+    a.flip_row = render_bottom_up ? -2 * a.chunks_per_row : 0;
+}
 
 hipError_t launch_table(float *table, int npix, hipStream_t stream);
 hipError_t launch_grid(const GridArgs &a, int workgroups, bool use_bg, hipStream_t stream);

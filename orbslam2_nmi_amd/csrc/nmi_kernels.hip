@@ -29,6 +29,7 @@ constexpr int kWords = kBins * kBins / 2;  // two 16-bit counters per LDS word
 constexpr int kOvfCap = 1024;              // >= 2 * floor(2^24 / 65536) + 1 wrap events per candidate
 constexpr int kRowsPerWave = kBins / kWaves;
 constexpr int kLdsTable = 4096;            // per-count entropy terms kept in LDS for counts below this
+constexpr int kSide = 8;                   // side counters for bins fed by flat image regions (see fold_flat_chunk)
 
 // LDS word of joint bin (d1 = render intensity, d2 = warped-frame intensity):
 //   word = d1 * 128 + (d2 & 127), low half for d2 < 128, high half for d2 >= 128.
@@ -44,6 +45,8 @@ struct Lds {
     uint32_t ovf[2][kOvfCap];     // wrap events: (word << 1) | field; double-buffered by candidate parity
     uint32_t ovf_n[2];
     uint32_t total[2];            // sum of all decoded counters of the candidate (wrap detector), by parity
+    uint32_t side_key[2][kSide];  // flat-region side counters: ((word << 1) | field) + 1, 0 = free; by candidate parity
+    uint32_t side_cnt[2][kSide];  // their 32-bit counts (added to the decoded counters in decode_phase)
     float table[kLdsTable];       // table[c] for c < kLdsTable (16 KiB); larger counts read the global table
     uint32_t fallback;            // pipelined kernel: a candidate wrapped, finish sequentially on the exact path
     uint32_t redo_n;
@@ -135,12 +138,83 @@ __device__ __forceinline__ void add_pixel(Lds &lds, int par, uint32_t d1, uint32
     if (__builtin_expect((old & field) == field, 0)) record_wrap(lds, par, word, val, old);
 }
 
+// Cheap necessary condition for a flat chunk, wavefront-uniform: first dword == last dword in both images for every
+// active lane (2 VALU compares + scalar work); the full test runs only where this holds.
+__device__ __forceinline__ bool flat_hint(const uint4 &rv, const uint4 &wv)
+{
+    // spelled out: from "__all(...)" hipcc builds compare, select 0/1, compare again, two scalar tests
+    unsigned long long m;
+    asm volatile("v_cmp_eq_u32 vcc, %1, %2\n\tv_cmp_eq_u32 %0, %3, %4\n\ts_and_b64 %0, %0, vcc"
+                 : "=s"(m)
+                 : "v"(rv.x), "v"(rv.w), "v"(wv.x), "v"(wv.w)
+                 : "vcc");
+    return m == __builtin_amdgcn_read_exec();
+}
+
+// Flat chunks.  When, for every active lane of the wavefront, all 16 pixels of the lane carry the same (render, frame)
+// pair -- render background over saturated sky or over the frame border, clipped regions -- the plain path would queue
+// 64 lanes on one LDS address 16 times over (2 cycles per lane each time: ~12x the cost of a textured chunk).  Folded,
+// the 16 updates of a lane become one weighted add, and if the whole wavefront agrees on the pair, one add by one lane
+// into a 32-bit side counter (kSide per candidate, replayed in decode_phase): a large flat region then neither
+// serialises the LDS nor wraps a 16-bit field, so such frames stay on the one-pass optimistic path.
+// Returns false (nothing done) when some active lane is not flat.
+__device__ __forceinline__ bool side_add(Lds &lds, int par, uint32_t word, uint32_t high, uint32_t weight)
+{
+    const uint32_t key1 = ((word << 1) | high) + 1u;
+    for (int e = 0; e < kSide; ++e) {
+        const uint32_t old = atomicCAS(&lds.side_key[par][e], 0u, key1);
+        if (old == 0u || old == key1) {
+            atomicAdd(&lds.side_cnt[par][e], weight);
+            return true;
+        }
+    }
+    return false;
+}
+
+template <bool BG, bool SHIFTED, int HIST>
+__device__ __forceinline__ bool fold_flat_chunk(Lds &lds, int par, const uint32_t (&r)[4], const uint32_t (&w)[4], int shift)
+{
+    const uint32_t rb = r[0] & 0xFFu, wb = w[0] & 0xFFu;
+    const bool flat = r[0] == r[1] && r[1] == r[2] && r[2] == r[3] && w[0] == w[1] && w[1] == w[2] && w[2] == w[3] &&
+                      r[0] == rb * 0x01010101u && w[0] == wb * 0x01010101u;
+    if (!__all(flat)) return false;
+    uint32_t d1 = rb, d2 = wb;
+    const bool skip = !BG && (d1 == 0 || d2 == 0);  // NMI.cu:85
+    if (SHIFTED) {
+        d1 >>= shift;
+        d2 >>= shift;
+    }
+    const uint32_t key = (d1 << 8) | d2;
+    const uint32_t key0 = __builtin_amdgcn_readfirstlane(key);
+    const bool skip0 = __builtin_amdgcn_readfirstlane((uint32_t)skip) != 0;
+    const uint32_t word = joint_word(d1, d2), high = d2 >> 7;
+    uint32_t weight = 16;
+    bool issue = !skip;
+    if (__all(key == key0 && skip == skip0)) {  // one lane speaks for the wavefront
+        const unsigned long long active = __ballot(1);
+        weight = 16u * (uint32_t)__popcll(active);
+        issue = issue && (__lane_id() == (uint32_t)__ffsll((long long)active) - 1u);
+        if (issue && side_add(lds, par, word, high, weight)) issue = false;
+    }
+    if (issue) {
+        const uint32_t inc = high ? weight << 16 : weight;
+        if (HIST == 2) {
+            (void)__hip_atomic_fetch_add(&lds.joint[word], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            const uint32_t old = __hip_atomic_fetch_add(&lds.joint[word], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t field_old = high ? old >> 16 : old & 0xFFFFu;
+            if (field_old + weight > 0xFFFFu) record_wrap(lds, par, word, high ? 0x10000u : 1u, high ? old : (old | 0xFFFFu));
+        }
+    }
+    return true;
+}
+
 // 16 pixels of one lane.  HIST selects how wraps of the 16-bit counters are handled:
 //   0  returning atomic + test per pixel (serialises on the LDS round trip; kept as the ablation baseline)
 //   1  16 returning atomics in flight, one combined wrap test per 16 pixels, flat chunks folded (the exact path)
 //   2  non-returning atomics, no test: exact only when no bin can exceed 65535 (first try of the
 //      optimistic scheme HIST = 3, see nmi_grid_kernel)
-template <bool BG, bool SHIFTED, int HIST>
+template <bool BG, bool SHIFTED, int HIST, bool FOLD>
 __device__ __forceinline__ void add_chunk(Lds &lds, int par, const uint4 &rv, const uint4 &wv, int shift, bool try_flat)
 {
     const uint32_t r[4] = {rv.x, rv.y, rv.z, rv.w};
@@ -153,43 +227,11 @@ __device__ __forceinline__ void add_chunk(Lds &lds, int par, const uint4 &rv, co
                 add_pixel<BG, SHIFTED>(lds, par, (r[q] >> (8 * j)) & 0xFFu, (w[q] >> (8 * j)) & 0xFFu, shift);
         return;
     }
-    // Flat chunks: when, for every active lane of the wavefront, all 16 pixels carry the same (render, frame) pair --
-    // render background over frame border, saturated regions -- the 16 updates of a lane collapse into one weighted
-    // add, and if the whole wavefront agrees on the pair, into a single add by one lane.  Otherwise 64 lanes would
-    // queue 16 times on one LDS address (2 cycles per lane each time).
-    // Only the exact path looks for them: it runs when a candidate has a bin above 65535 hits, which is exactly the data
-    // that has such regions, and the test costs ~10 % of the histogram phase when it never fires.
-    if (HIST == 1 && try_flat) {
-        const uint32_t rb = r[0] & 0xFFu, wb = w[0] & 0xFFu;
-        const bool flat = r[0] == r[1] && r[1] == r[2] && r[2] == r[3] && w[0] == w[1] && w[1] == w[2] && w[2] == w[3] &&
-                          r[0] == rb * 0x01010101u && w[0] == wb * 0x01010101u;
-        if (__builtin_expect(__all(flat), 0)) {
-            uint32_t d1 = rb, d2 = wb;
-            const bool skip = !BG && (d1 == 0 || d2 == 0);  // NMI.cu:85
-            if (SHIFTED) {
-                d1 >>= shift;
-                d2 >>= shift;
-            }
-            const uint32_t key = (d1 << 8) | d2;
-            const uint32_t key0 = __builtin_amdgcn_readfirstlane(key);
-            const bool skip0 = __builtin_amdgcn_readfirstlane((uint32_t)skip) != 0;
-            uint32_t weight = 16;
-            bool issue = !skip;
-            if (__all(key == key0 && skip == skip0)) {  // one lane speaks for the wavefront
-                weight = 16u * (uint32_t)__popcll(__ballot(1));
-                issue = issue && (__lane_id() == (uint32_t)__ffsll((long long)__ballot(1)) - 1u);
-            }
-            if (issue) {
-                const uint32_t word = joint_word(d1, d2), high = d2 >> 7, inc = high ? weight << 16 : weight;
-                if (HIST == 2) {
-                    (void)__hip_atomic_fetch_add(&lds.joint[word], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                } else {
-                    const uint32_t old = __hip_atomic_fetch_add(&lds.joint[word], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    const uint32_t field_old = high ? old >> 16 : old & 0xFFFFu;
-                    if (field_old + weight > 0xFFFFu) record_wrap(lds, par, word, high ? 0x10000u : 1u, high ? old : (old | 0xFFFFu));
-                }
-            }
-            return;
+    // Flat chunks (render background over saturated sky or frame border, ...) are folded, see fold_flat_chunk; only the
+    // careful loop of histogram_phase asks for it.
+    if (FOLD && HIST != 0 && try_flat) {
+        if (__builtin_expect(flat_hint(rv, wv), 0)) {
+            if (fold_flat_chunk<BG, SHIFTED, HIST>(lds, par, r, w, shift)) return;
         }
     }
     if (HIST == 2 && BG && !SHIFTED) {
@@ -275,7 +317,7 @@ __device__ __forceinline__ void add_chunk(Lds &lds, int par, const uint4 &rv, co
 
 // Histogram phase for one candidate: histogram256Kernel's pixel loop, NMI.cu:79-87.
 // NT lanes (tid = 0..NT-1) share the pixels of the candidate.
-template <bool BG, bool SHIFTED, int HIST, int NT>
+template <bool BG, bool SHIFTED, int HIST, int NT, bool FOLD = true>
 __device__ __forceinline__ void histogram_phase(Lds &lds, int par, const GridArgs &a, const uint8_t *__restrict__ render,
                                                 const uint8_t *__restrict__ warped, int tid)
 {
@@ -283,34 +325,62 @@ __device__ __forceinline__ void histogram_phase(Lds &lds, int par, const GridArg
         // 16 pixels per lane per step: one 16-byte load from each image (1 KiB per wavefront instruction),
         // the next step's loads issued before this step's atomics.
         const int nchunks = a.npix >> 4;
-        const uint4 *__restrict__ wp = reinterpret_cast<const uint4 *>(warped);
-        const uint4 *__restrict__ rp = reinterpret_cast<const uint4 *>(render);
-        auto render_chunk = [&](int ch) {
-            if (!a.flip) return ch;
-            // NMI.cu:82: row y of the frame meets row H-1-y of the bottom-up render
-            const int y = (a.chunks_per_row == 1) ? ch : (int)__umulhi((uint32_t)ch, a.cpr_magic);
-            return (a.height - 1 - y) * a.chunks_per_row + (ch - y * a.chunks_per_row);
+        // 32-bit unsigned byte offsets from the (scalar) image bases: one shift per load instead of 64-bit pointer math
+        auto ldw = [&](int c) { return *reinterpret_cast<const uint4 *>(warped + ((uint32_t)c << 4)); };
+        // NMI.cu:82: row y of the frame meets row H-1-y of a bottom-up render.  Branch-free for both orientations:
+        // render chunk = c + flip_base + y * flip_row with y = c / chunks_per_row (multiply-high by the magic).
+        auto ldr = [&](int c) {
+            const int y = (int)__umulhi((uint32_t)c, a.cpr_magic);
+            return *reinterpret_cast<const uint4 *>(render + ((uint32_t)(__mul24(y, a.flip_row) + c + a.flip_base) << 4));
         };
-        // Software pipeline with two named register sets: the loads of the chunk after next are in flight while
-        // the current chunk's 16 atomics issue (a third set measured no faster and costs 8 VGPRs).  Loads are
+        // Fast loop.  Software pipeline with two named register sets: the loads of the chunk after next are in flight
+        // while the current chunk's 16 atomics issue (a third set measured no faster and costs 8 VGPRs).  Loads are
         // unconditional (index clamped to the last chunk, a valid address) so the code is straight-line and the
         // compiler can wait on exact load counts; only the atomics are predicated on the chunk being in range.
-        const bool try_flat = !(a.phase_mask & 4);  // ablation switch for the flat-chunk shortcut
+        // The only trace of the flat-region handling in here is flat_hint + a branch that is never taken on textured
+        // content: on a hit the wavefront leaves for the careful loop below and stays there for the rest of this
+        // candidate (everything the fold needs inside this loop cost 5-11 % of the whole kernel).
+        constexpr bool kHint = FOLD && HIST != 0;
+        const bool try_flat = kHint && !(a.phase_mask & 4);  // bit 2: ablation switch (careful loop entered, nothing folded)
         const int last = nchunks - 1;
         const int iters = (nchunks + NT - 1) / NT;  // workgroup-uniform
-        int ch = tid;
-        int c0 = min(ch, last);
-        uint4 wa = wp[c0], ra = rp[render_chunk(c0)], wb, rb;
-        for (int it = 0; it < iters; it += 2) {
-            const int c1 = min(ch + NT, last);
-            wb = wp[c1];
-            rb = rp[render_chunk(c1)];
-            if (ch < nchunks) add_chunk<BG, SHIFTED, HIST>(lds, par, ra, wa, a.shift, try_flat);
-            const int c2 = min(ch + 2 * NT, last);
-            wa = wp[c2];
-            ra = rp[render_chunk(c2)];
-            if (ch + NT < nchunks) add_chunk<BG, SHIFTED, HIST>(lds, par, rb, wb, a.shift, try_flat);
-            ch += 2 * NT;
+        int resume = (HIST == 1 && kHint) ? tid : -1;  // the exact path is cold anyway: careful from the start
+        if (resume < 0) {
+            int ch = tid;
+            int c0 = min(ch, last);
+            uint4 wa = ldw(c0), ra = ldr(c0), wb, rb;
+            for (int it = 0; it < iters; it += 2) {
+                const int c1 = min(ch + NT, last);
+                wb = ldw(c1);
+                rb = ldr(c1);
+                if (kHint && __builtin_expect(flat_hint(ra, wa), 0)) {
+                    resume = ch;
+                    break;
+                }
+                if (ch < nchunks) add_chunk<BG, SHIFTED, HIST, false>(lds, par, ra, wa, a.shift, false);
+                const int c2 = min(ch + 2 * NT, last);
+                wa = ldw(c2);
+                ra = ldr(c2);
+                if (kHint && __builtin_expect(flat_hint(rb, wb), 0)) {
+                    resume = ch + NT;
+                    break;
+                }
+                if (ch + NT < nchunks) add_chunk<BG, SHIFTED, HIST, false>(lds, par, rb, wb, a.shift, false);
+                ch += 2 * NT;
+            }
+        }
+        if (resume >= 0) {
+            // Careful loop: same adds, flat chunks folded; one chunk of prefetch.
+            int c = min(resume, last);
+            uint4 wc = ldw(c), rc = ldr(c);
+#pragma unroll 1
+            for (int ch = resume; ch < nchunks; ch += NT) {
+                const int cn = min(ch + NT, last);
+                const uint4 wn = ldw(cn), rn = ldr(cn);
+                add_chunk<BG, SHIFTED, HIST, true>(lds, par, rc, wc, a.shift, try_flat);
+                wc = wn;
+                rc = rn;
+            }
         }
     } else {
         // Any width / alignment: byte loads, position arithmetic as written in NMI.cu:79-83.
@@ -374,6 +444,7 @@ __device__ __forceinline__ void apply_wraps(const Lds &lds, int par, uint32_t no
 __device__ __forceinline__ void decode_phase(Lds &lds, int par, const GridArgs &a, int wave, int lane)
 {
     const uint32_t novf = lds.ovf_n[par] < (uint32_t)kOvfCap ? lds.ovf_n[par] : (uint32_t)kOvfCap;
+    const bool side_any = lds.side_key[par][0] != 0u;
     uint32_t wave_total = 0;
     const int i = lane & 15, r = lane >> 4, o = r & 1;
     uint32_t col_lo[8], col_hi[8];
@@ -395,6 +466,25 @@ __device__ __forceinline__ void decode_phase(Lds &lds, int par, const GridArgs &
         if (__builtin_expect(novf != 0, 0)) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) apply_wraps(lds, par, novf, k < 7 ? a0 + 16 * k : a0 + 112 - 128 * o, lo[k], hi[k]);
+        }
+        if (__builtin_expect(side_any, 0)) {
+            // side counters of flat regions (fold_flat_chunk): entries fill in order, a free one ends the list
+            for (int e = 0; e < kSide; ++e) {
+                const uint32_t key1 = __builtin_amdgcn_readfirstlane(lds.side_key[par][e]);
+                if (key1 == 0u) break;
+                const uint32_t sword = (key1 - 1u) >> 1;
+                if ((sword >> 9) != (uint32_t)((wave * kRowsPerWave + pass * 4) >> 2)) continue;  // not among this pass's 4 rows
+                const uint32_t cnt = lds.side_cnt[par][e];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if ((k < 7 ? a0 + 16 * k : a0 + 112 - 128 * o) == sword) {
+                        if ((key1 - 1u) & 1u)
+                            hi[k] += cnt;
+                        else
+                            lo[k] += cnt;
+                    }
+                }
+            }
         }
         uint32_t rsum = 0, cmax = 0;
         float tl[8], th[8];
@@ -521,6 +611,7 @@ __device__ __forceinline__ void exact_candidate(Lds &lds, const GridArgs &a, int
         final_phase(lds, a, lane, p, w, s, prev_key);
         for (int t = lane; t < kBins; t += 64) lds.hist_warped[t] = 0;
         if (lane == 0) lds.ovf_n[0] = lds.total[0] = 0;
+        if (lane < kSide) lds.side_key[0][lane] = lds.side_cnt[0][lane] = 0;
     }
     __syncthreads();
 }
@@ -564,6 +655,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
     }
     if (tid < kBins) lds.hist_warped[tid] = 0;
     if (tid < 2) lds.ovf_n[tid] = lds.total[tid] = 0;
+    if (tid < 2 * kSide) (&lds.side_key[0][0])[tid] = (&lds.side_cnt[0][0])[tid] = 0;
     bool table_pending = true;
     int exact_from = -1;  // first ordinal of this workgroup that needs the exact path (workgroup-uniform)
     __syncthreads();
@@ -607,6 +699,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
                 lds.ovf_n[par] = 0;       // consumed by this candidate's decode; next used two candidates on
                 lds.total[par ^ 1] = 0;   // read by everyone right after the previous B2; next candidate adds to it
             }
+            if (lane < kSide) lds.side_key[par][lane] = lds.side_cnt[par][lane] = 0;  // like ovf_n[par]
         }
     }
 
@@ -614,6 +707,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
         __syncthreads();  // everyone has read the failed total; wavefront 0 is past the previous candidate's final phase
         if (tid < kBins) lds.hist_warped[tid] = 0;
         if (tid < 2) lds.total[tid] = lds.ovf_n[tid] = 0;
+        if (tid < 2 * kSide) (&lds.side_key[0][0])[tid] = (&lds.side_cnt[0][0])[tid] = 0;
         __syncthreads();
         for (int o = exact_from; o < total; o += gridDim.x) exact_candidate<SHIFTED>(lds, a, tid, candidate_at(a, o), prev_key);
     }
@@ -776,6 +870,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel_ws(GridArgs
     for (int c = tid; c < kLdsTable; c += kBlock) lds.table[c] = a.table[c <= a.npix ? c : 0];
     if (tid < kBins) lds.hist_warped[tid] = 0;
     if (tid < 2) lds.ovf_n[tid] = lds.total[tid] = 0;
+    if (tid < 2 * kSide) (&lds.side_key[0][0])[tid] = (&lds.side_cnt[0][0])[tid] = 0;
     if (tid == 0) lds.fallback = lds.redo_n = 0;
     __syncthreads();
 
@@ -793,7 +888,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel_ws(GridArgs
         if (is_hist) {
             if (k < n && (a.phase_mask & 1)) {
                 const int w = p / a.S_local, s = p - w * a.S_local;
-                histogram_phase<true, SHIFTED, 2, kHalf>(lds, 0, a, a.render_stack + (size_t)s * a.npix,
+                histogram_phase<true, SHIFTED, 2, kHalf, false>(lds, 0, a, a.render_stack + (size_t)s * a.npix,
                                                          a.warp_stack + (size_t)w * a.npix, tid);
             }
         } else if (k > 0 && (a.phase_mask & 2)) {

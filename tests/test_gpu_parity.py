@@ -151,6 +151,76 @@ def test_counter_wrap_cases(nmi):
         check_pair(nmi, oc, r, f, bg=False, bu=True)
 
 
+def _banded(h, w, values, band):
+    """Image of horizontal bands of `band` rows with the given constant values (cycled)."""
+    rows = np.array([values[(y // band) % len(values)] for y in range(h)], np.uint8)
+    return np.repeat(rows[:, None], w, axis=1)
+
+
+def test_flat_regions_are_folded_exactly(nmi):
+    """Regions where both images are constant are folded into weighted adds / 32-bit side counters (fold_flat_chunk):
+    few pairs, more distinct pairs than side counters, flat next to texture, flat bins that also collect textured hits
+    and exceed 65535, every switch that changes the pixel rule."""
+    from oracle import binding as oc
+    from orbslam2_nmi_amd import synthetic as sy
+    w, h = 640, 480
+    rng = np.random.default_rng(5)
+    B = sy.scene(w, h, 41)
+    tex_r, tex_f = sy.render_stack(B, (1, 1, 1))[0], sy.camera_frame(B, 42)
+    cases = []
+    # sky: 30 % of the rows flat in both images, the rest textured
+    r, f = tex_r.copy(), tex_f.copy()
+    r[:144], f[:144] = 255, 255
+    cases.append((r, f))
+    # 20 bands of 24 rows, 20 distinct (render, frame) pairs: more than the 8 side counters
+    cases.append((_banded(h, w, list(range(10, 210, 10)), 24), _banded(h, w, list(range(250, 50, -10)), 24)))
+    # bands of 2 rows (1280 px): wavefront-wide agreement only sometimes, lane-level folds mostly
+    cases.append((_banded(h, w, [255, 0, 77], 2), _banded(h, w, [0, 255, 200, 130], 2)))
+    # vertical stripes 16 px wide: every lane flat, neighbours differ (no wavefront-wide pair)
+    stripes = np.repeat((np.arange(w // 16) % 7 * 30).astype(np.uint8), 16)[None, :].repeat(h, 0)
+    cases.append((stripes, stripes[:, ::-1].copy()))
+    # flat region whose bin also receives scattered textured hits; total above 65535 (high and low field)
+    for val in (200, 3):
+        r = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        f = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        r[100:330], f[100:330] = 255, val           # 147200 flat hits
+        m = rng.random((h, w)) < 0.05
+        r[m], f[m] = 255, val
+        cases.append((r, f))
+    # zeros: skipped pixels when the background rule is off
+    r, f = tex_r.copy(), tex_f.copy()
+    r[200:], f[300:] = 0, 0
+    cases.append((r, f))
+    for r, f in cases:
+        check_pair(nmi, oc, r, f, bu=False)
+        check_pair(nmi, oc, r, f, bg=False, bu=True)
+        check_pair(nmi, oc, r, f, bins=32, bu=True)
+
+
+def test_flat_regions_in_a_grid(nmi):
+    """The grid kernel on stacks with large flat regions: rating table and winner equal the oracle's, with folding on
+    and off (NMI_OPT_PHASE_MASK bit 2), so the two code paths are compared with each other too."""
+    from oracle import binding as oc
+    from orbslam2_nmi_amd import synthetic as sy
+    w, h, S, Wn = 320, 240, 6, 5
+    wl = sy.workload(w, h, S, Wn, seed=9)
+    rs, ws = wl["render_stack"].copy(), wl["warp_stack"].copy()
+    rs[:, : h // 3] = 255          # bottom-up renders: these rows meet the frame's last third
+    ws[:, -(h // 3):] = 255
+    ws[2, : h // 2] = 0
+    rs[3, h // 2:] = 255           # render 3 over warp 2: flat (255, 0) as well
+    ref = np.array([[oc.eval_pair(rs[s], ws[v]) for s in range(S)] for v in range(Wn)], np.float32)
+    ibest, vbest = oc.find_max(ref)
+    with nmi.NmiContext(w, h) as ctx:
+        for mask in (3, 7):
+            ctx.set_option(ctx.OPT_PHASE_MASK, mask)
+            ratings = torch.empty((Wn, S), dtype=torch.float32, device="cuda")
+            idx, val = ctx.search_grid(dev(rs), dev(ws), ratings=ratings)
+            got = ratings.cpu().numpy()
+            assert np.abs(got - ref).max() <= SCORE_TOL, mask
+            assert idx == ibest and abs(val - float(vbest)) <= SCORE_TOL, mask
+
+
 def test_grid_golden(nmi, golden_grid):
     g = golden_grid
     rs, ws = g["render_stack"], g["warp_stack"]
