@@ -10,7 +10,8 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 LIB_DIR = os.path.join(PKG, "lib")
-LIB = os.path.join(LIB_DIR, "libnmi_hip.so")
+# NMI_HIP_LIBRARY points the loader at another build of the same ABI (A/B timing of kernel variants on one box).
+LIB = os.environ.get("NMI_HIP_LIBRARY") or os.path.join(LIB_DIR, "libnmi_hip.so")
 ARCH = "gfx950"
 
 
@@ -33,6 +34,8 @@ def headers():
 
 
 def is_stale():
+    if os.environ.get("NMI_HIP_LIBRARY"):
+        return False
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)

@@ -538,18 +538,26 @@ __device__ __forceinline__ void final_phase(Lds &lds, const GridArgs &a, int lan
 {
     const int i = lane & 15, r = lane >> 4;
     float lo[8], hi[8];
+    // All 16 table lookups of a lane are issued back to back and unconditionally (table[0] = 0; rows 2, 3 fetch
+    // table[0] and discard it): one memory round trip (1.0 us) instead of one per conditional lookup (2.5 us).  The
+    // other wavefronts are already adding the next candidate's pixels and wait for this one at the next barrier.
+    const uint32_t *h = r == 0 ? lds.hist_render : lds.hist_warped;
+    uint32_t cl[8], ch[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const int t = i + 16 * k;
-        if (r == 2) {
-            lo[k] = lds.joint_row_sums[t];
-            hi[k] = lds.joint_row_sums[t + 128];
-        } else if (r < 2) {
-            const uint32_t *h = r == 0 ? lds.hist_render : lds.hist_warped;
-            lo[k] = term(a.table, h[t]);
-            hi[k] = term(a.table, h[t + 128]);
-        } else {
-            lo[k] = hi[k] = 0.0f;
+        cl[k] = r < 2 ? h[i + 16 * k] : 0u;
+        ch[k] = r < 2 ? h[i + 16 * k + 128] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        lo[k] = a.table[cl[k]];
+        hi[k] = a.table[ch[k]];
+    }
+    if (r == 2) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            lo[k] = lds.joint_row_sums[i + 16 * k];
+            hi[k] = lds.joint_row_sums[i + 16 * k + 128];
         }
     }
     const float x = row_tree_16(lane_tree_16(lo, hi));
