@@ -707,7 +707,11 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
                 lds.ovf_n[par] = 0;       // consumed by this candidate's decode; next used two candidates on
                 lds.total[par ^ 1] = 0;   // read by everyone right after the previous B2; next candidate adds to it
             }
-            if (lane < kSide) lds.side_key[par][lane] = lds.side_cnt[par][lane] = 0;  // like ovf_n[par]
+            if (lane < kSide) {  // like ovf_n[par]
+                int l = lane;
+                asm volatile("" : "+v"(l));  // keep the two addresses out of long-lived (spilled) registers
+                lds.side_key[par][l] = lds.side_cnt[par][l] = 0;
+            }
         }
     }
 
