@@ -1,7 +1,8 @@
 """Builds orbslam2_nmi_amd/lib/libnmi_hip.so (gfx950) in-tree with hipcc.
 
-The shared library is the product: HIP kernels (csrc/nmi_kernels.hip) + the C ABI of include/nmi_hip.h
-(csrc/nmi_capi.cpp) + the host-side mirror of the reference's driver types (host/*.cpp).
+The shared library is the product: HIP kernels (csrc/nmi_kernels.hip scoring, csrc/nmi_producers.hip warp / render
+stacks) + the C ABI of include/nmi_hip.h (csrc/nmi_capi*.cpp over csrc/nmi_ctx.h) + the host-side mirror of the
+reference's driver types (host/*.cpp, include/nmi_host.h).
 """
 import os
 import subprocess

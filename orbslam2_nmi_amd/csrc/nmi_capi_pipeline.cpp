@@ -8,8 +8,12 @@ extern "C" {
 
 // ---------------------------------------------------------------------------------------------------------
 // One search level as a captured HIP graph: cloud -> S renders, frame -> Wn warps, grid search, winner to the host.
-// Seven dependent operations (two parameter uploads, clear, splat, resolve, warp, key reset + search, winner copy)
-// replay with one hipGraphLaunch; only the pinned parameter buffers change between replays.
+// Five kernel nodes and no copy nodes replay with one hipGraphLaunch:
+//   prep (reads the pinned parameter buffers, resets the key, clears the anchor buffer)
+//     -> splat -> resolve  \
+//     -> warp (forked branch: it only needs the frame and its coefficients, and hides behind the VALU-bound splat)
+//                           -> search, whose last workgroup stores the winner into pinned host memory.
+// Only the pinned parameter buffers change between replays; the caller polls the winner word.
 // ---------------------------------------------------------------------------------------------------------
 }  // extern "C"
 
@@ -22,6 +26,8 @@ struct nmi_level {
     int *d_order = nullptr;
     unsigned long long *d_key = nullptr, *h_key = nullptr;
     unsigned int *d_done = nullptr;
+    hipStream_t side = nullptr;                 // forked capture branch (warp)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
 };
@@ -41,6 +47,9 @@ int nmi_level_destroy(nmi_level *lv)
     void *host[] = {lv->h_mvps, lv->h_coeffs, lv->h_key};
     for (void *q : host)
         if (q) (void)hipHostFree(q);
+    if (lv->ev_fork) (void)hipEventDestroy(lv->ev_fork);
+    if (lv->ev_join) (void)hipEventDestroy(lv->ev_join);
+    if (lv->side) (void)hipStreamDestroy(lv->side);
     delete lv;
     return NMI_OK;
 }
@@ -77,9 +86,13 @@ int nmi_level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int64
     ok(hipMalloc((void **)&lv->d_order, (size_t)total * sizeof(int)));
     ok(hipMalloc((void **)&lv->d_key, sizeof(unsigned long long)));
     ok(hipMalloc((void **)&lv->d_done, sizeof(unsigned int)));
-    ok(hipHostMalloc((void **)&lv->h_mvps, (size_t)S * 16 * sizeof(float), hipHostMallocDefault));
-    ok(hipHostMalloc((void **)&lv->h_coeffs, (size_t)Wn * 9 * sizeof(float), hipHostMallocDefault));
-    ok(hipHostMalloc((void **)&lv->h_key, sizeof(unsigned long long), hipHostMallocDefault));
+    // pinned, device-mapped, fine-grained: the prep kernel reads the parameters and the search kernel posts the winner
+    ok(hipHostMalloc((void **)&lv->h_mvps, (size_t)S * 16 * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
+    ok(hipHostMalloc((void **)&lv->h_coeffs, (size_t)Wn * 9 * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
+    ok(hipHostMalloc((void **)&lv->h_key, sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+    ok(hipStreamCreateWithFlags(&lv->side, hipStreamNonBlocking));
+    ok(hipEventCreateWithFlags(&lv->ev_fork, hipEventDisableTiming));
+    ok(hipEventCreateWithFlags(&lv->ev_join, hipEventDisableTiming));
     int *order = e == hipSuccess ? new (std::nothrow) int[(size_t)total] : nullptr;
     if (e != hipSuccess || !order) {
         const int rc = e != hipSuccess ? hip_fail(ctx, e, "nmi_level_create") : NMI_ERR_INVALID_ARGUMENT;
@@ -106,23 +119,34 @@ int nmi_level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int64
     a.mode = p.mode;
     a.table = ctx->table;
     a.order = lv->d_order;
-    a.key = lv->d_key;        // reset by a memset node before every replay (the ping-pong of plain launches needs
+    a.key = lv->d_key;        // reset by the prep node before every replay (the ping-pong of plain launches needs
     a.reset_key = nullptr;    // alternating arguments, which a replayed graph does not have)
     a.done = lv->d_done;
+    float *hd_mvps = nullptr, *hd_coeffs = nullptr;
+    unsigned long long *hd_key = nullptr;
+    if (e == hipSuccess) {
+        ok(hipHostGetDevicePointer((void **)&hd_mvps, lv->h_mvps, 0));
+        ok(hipHostGetDevicePointer((void **)&hd_coeffs, lv->h_coeffs, 0));
+        ok(hipHostGetDevicePointer((void **)&hd_key, lv->h_key, 0));
+    }
+    a.out_key = hd_key;
     a.hist_variant = 3;
     a.phase_mask = 3;
     const int cap = ctx->workgroups > 0 ? ctx->workgroups : ctx->compute_units;
     const int workgroups = (int)(total < cap ? total : cap);
 
     hipStream_t st = ctx->stream;
-    if (ok(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal))) {
-        ok(hipMemcpyAsync(lv->d_mvps, lv->h_mvps, (size_t)S * 16 * sizeof(float), hipMemcpyHostToDevice, st));
-        ok(nmi::launch_render_points(d_xyz, d_red, n_points, lv->d_mvps, S, lv->d_zbuf, lv->d_renders, p.width, p.height, lv->size, st));
-        ok(hipMemcpyAsync(lv->d_coeffs, lv->h_coeffs, (size_t)Wn * 9 * sizeof(float), hipMemcpyHostToDevice, st));
-        ok(nmi::launch_warp(d_frame, lv->d_coeffs, lv->d_warps, p.width, p.height, Wn, st));
-        ok(hipMemsetAsync(lv->d_key, 0, sizeof(unsigned long long), st));
+    if (e == hipSuccess && ok(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal))) {
+        ok(nmi::launch_level_prep(hd_mvps, lv->d_mvps, S * 16, hd_coeffs, lv->d_coeffs, Wn * 9, lv->d_key, lv->d_zbuf,
+                                  nmi::render_zbuf_words(S, p.width, p.height, lv->size), st));
+        ok(hipEventRecord(lv->ev_fork, st));
+        ok(hipStreamWaitEvent(lv->side, lv->ev_fork, 0));
+        ok(nmi::launch_warp(d_frame, lv->d_coeffs, lv->d_warps, p.width, p.height, Wn, lv->side));
+        ok(hipEventRecord(lv->ev_join, lv->side));
+        ok(nmi::launch_render_points(d_xyz, d_red, n_points, lv->d_mvps, S, lv->d_zbuf, lv->d_renders, p.width, p.height, lv->size, st,
+                                     /*clear_first=*/false));
+        ok(hipStreamWaitEvent(st, lv->ev_join, 0));
         ok(nmi::launch_grid(a, workgroups, true, st));
-        ok(hipMemcpyAsync(lv->h_key, lv->d_key, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         hipError_t ec = hipStreamEndCapture(st, &lv->graph);
         ok(ec);
     }
@@ -153,9 +177,25 @@ int nmi_level_run(nmi_level *lv, const float *h_mvps, const double *h_forward, i
                                (m[3] * m[7] - m[4] * m[6]) / det, (m[1] * m[6] - m[0] * m[7]) / det, (m[0] * m[4] - m[1] * m[3]) / det};
         for (int k = 0; k < 9; ++k) lv->h_coeffs[w * 9 + k] = (float)inv[k];
     }
+    // The search kernel's last workgroup stores the winner (never all ones: scores are non-negative floats) into
+    // *h_key with system scope; polling that word returns ~10 us earlier than waiting for the stream to drain.
+    constexpr unsigned long long kPending = ~0ull;
+    __atomic_store_n(lv->h_key, kPending, __ATOMIC_RELEASE);
     NMI_HIP_TRY(ctx, hipGraphLaunch(lv->exec, ctx->stream));
-    NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return nmi_key_unpack(*lv->h_key, h_best_index, h_best_score);
+    unsigned long long key = kPending;
+    for (uint64_t spin = 0; key == kPending; ++spin) {
+        key = __atomic_load_n(lv->h_key, __ATOMIC_ACQUIRE);
+        if (key == kPending && (spin & 0xFFFF) == 0xFFFF) {
+            const hipError_t q = hipStreamQuery(ctx->stream);  // a faulted or finished stream must not leave us spinning
+            if (q == hipSuccess) {
+                key = __atomic_load_n(lv->h_key, __ATOMIC_ACQUIRE);
+                break;
+            }
+            if (q != hipErrorNotReady) return hip_fail(ctx, q, "hipStreamQuery");
+        }
+    }
+    if (key == kPending) return NMI_ERR_HIP;  // the graph ran without posting: cannot happen with a non-empty grid
+    return nmi_key_unpack(key, h_best_index, h_best_score);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -71,8 +71,14 @@ hipError_t launch_warp(const uint8_t *frame, const float *coeffs /*[Wn][9] inver
 hipError_t launch_render_mesh(const float *xyz, const float *uv, long long ntri, const float *luma, int levels, const int *lw,
                               const int *lh, const long long *loff, const float *mvps /*[S][16]*/, int S, uint32_t *zbuf /*[S][H][W]*/,
                               uint8_t *out, int width, int height, hipStream_t stream);
+// Words between rows of the renderers' anchor / depth buffer: the padded width, rounded so that the resolve pass can
+// read 8 consecutive anchors of any output quad with two aligned 16-byte loads (point sizes > 1); width for size 1.
+inline int zbuf_stride(int width, int size) { return size > 1 ? ((width + size - 1 + 3) & ~3) + 4 : width; }
 size_t render_zbuf_words(int S, int width, int height, int size);
 hipError_t launch_render_points(const float *xyz, const float *red, long long npoints, const float *mvps /*[S][16] column-major*/,
-                                int S, uint32_t *zbuf /*[render_zbuf_words]*/, uint8_t *out, int width, int height, int size, hipStream_t stream);
+                                int S, uint32_t *zbuf /*[render_zbuf_words]*/, uint8_t *out, int width, int height, int size, hipStream_t stream,
+                                bool clear_first = true);
+hipError_t launch_level_prep(const float *h_mvps, float *d_mvps, int n_mvps, const float *h_coeffs, float *d_coeffs, int n_coeffs,
+                             unsigned long long *key, uint32_t *zbuf, size_t nz, hipStream_t stream);
 
 }  // namespace nmi

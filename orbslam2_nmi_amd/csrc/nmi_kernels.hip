@@ -736,7 +736,8 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
         if (arrived == gridDim.x - 1) {
             const unsigned long long final_key = __hip_atomic_load(a.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a.out_key) *a.out_key = final_key;
+            if (a.out_key)  // may be pinned host memory that a caller polls (nmi_level_run)
+                __hip_atomic_store(a.out_key, final_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (a.mailbox)
                 __hip_atomic_store(&a.mailbox->word, final_key | ((unsigned long long)(a.seq & 1u) << 63), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_SYSTEM);
@@ -960,7 +961,8 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel_ws(GridArgs
         if (arrived == gridDim.x - 1) {
             const unsigned long long final_key = __hip_atomic_load(a.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a.out_key) *a.out_key = final_key;
+            if (a.out_key)  // may be pinned host memory that a caller polls (nmi_level_run)
+                __hip_atomic_store(a.out_key, final_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (a.mailbox)
                 __hip_atomic_store(&a.mailbox->word, final_key | ((unsigned long long)(a.seq & 1u) << 63), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_SYSTEM);

@@ -98,13 +98,40 @@ __global__ __launch_bounds__(256) void nmi_zbuf_clear_kernel(uint32_t *zbuf, siz
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) zbuf[i] = 0xFFFFFFFFu;
 }
 
+// First node of a captured search level (nmi_level_*): what would otherwise be two parameter uploads, a key reset
+// and the buffer clear -- four graph nodes with a hand-over each -- as one kernel.  The parameters are read straight
+// from the caller's pinned (device-mapped) buffers.
+__global__ __launch_bounds__(256) void nmi_level_prep_kernel(const float *__restrict__ h_mvps, float *__restrict__ d_mvps, int n_mvps,
+                                                             const float *__restrict__ h_coeffs, float *__restrict__ d_coeffs, int n_coeffs,
+                                                             unsigned long long *key, uint32_t *zbuf, size_t nz)
+{
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < n_mvps; i += blockDim.x) d_mvps[i] = h_mvps[i];
+        for (int i = threadIdx.x; i < n_coeffs; i += blockDim.x) d_coeffs[i] = h_coeffs[i];
+        if (threadIdx.x == 0) *key = 0ull;
+    }
+    uint4 *z4 = reinterpret_cast<uint4 *>(zbuf);
+    const uint4 ones = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    for (size_t i = t; i < nz / 4; i += step) z4[i] = ones;
+    for (size_t i = (nz & ~(size_t)3) + t; i < nz; i += step) zbuf[i] = 0xFFFFFFFFu;
+}
+
+hipError_t launch_level_prep(const float *h_mvps, float *d_mvps, int n_mvps, const float *h_coeffs, float *d_coeffs, int n_coeffs,
+                             unsigned long long *key, uint32_t *zbuf, size_t nz, hipStream_t stream)
+{
+    hipLaunchKernelGGL(nmi_level_prep_kernel, dim3(2048), dim3(256), 0, stream, h_mvps, d_mvps, n_mvps, h_coeffs, d_coeffs, n_coeffs, key,
+                       zbuf, nz);
+    return hipGetLastError();
+}
+
 // One lane per point, looping over the S views: the cloud is read once, not once per view (27 views of a 3 M-point
 // cloud would otherwise stream 1.3 GB per level); the S matrices sit in LDS.
 constexpr int kMaxViewsPerLaunch = 64;
 
 __global__ __launch_bounds__(256) void nmi_splat_kernel(const float *__restrict__ xyz, const float *__restrict__ red, long long npoints,
                                                         const float *__restrict__ mvps, int views, uint32_t *__restrict__ zbuf,
-                                                        int width, int height, int size)
+                                                        int width, int height, int size, int stride)
 {
     __shared__ float m_all[kMaxViewsPerLaunch * 16];
     for (int t = threadIdx.x; t < views * 16; t += blockDim.x) m_all[t] = mvps[t];  // column-major like glm: m[c*4 + r]
@@ -142,14 +169,46 @@ __global__ __launch_bounds__(256) void nmi_splat_kernel(const float *__restrict_
         // straddling the left / bottom edge keep their anchor.
         const int ax = x0 + size - 1, ay = y0 + size - 1, wp = width + size - 1, hp = height + size - 1;
         if (ax < 0 || ax >= wp || ay < 0 || ay >= hp) continue;
-        atomicMin(&zbuf[(size_t)s * wp * hp + (size_t)ay * wp + ax], frag);
+        atomicMin(&zbuf[((size_t)s * hp + ay) * stride + ax], frag);
     }
 }
 
-// Four horizontally adjacent output pixels per lane: the size x (size+3) anchor window is read once and the four
-// results leave as one dword.
+// Resolve.  Four horizontally adjacent output pixels per lane: the size x (size+3) anchor window is read once and the
+// four results leave as one dword.  Rows of the anchor buffer are `stride` words apart (zbuf_stride: padded so that a
+// lane can fetch its window as two aligned 16-byte loads per row).
+template <int SIZE>
+__global__ __launch_bounds__(256) void nmi_zbuf_resolve_fast_kernel(const uint32_t *__restrict__ zbuf, uint8_t *__restrict__ out, int views,
+                                                                    int width, int height, int stride)
+{
+    // requires width % 4 == 0, SIZE <= 5, stride % 4 == 0 and (SIZE == 1 or stride >= width + 4)
+    const int hp = height + SIZE - 1;
+    const int quads = width >> 2;
+    const size_t n = (size_t)views * height * quads;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % quads), py = (int)((i / quads) % height), s = (int)(i / ((size_t)quads * height));
+        const uint32_t *base = zbuf + ((size_t)s * hp + py) * stride + q * 4;
+        uint32_t best[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+#pragma unroll
+        for (int dy = 0; dy < SIZE; ++dy) {
+            const uint4 lo = *reinterpret_cast<const uint4 *>(base + (size_t)dy * stride);
+            uint32_t v[8] = {lo.x, lo.y, lo.z, lo.w, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            if (SIZE > 1) {
+                const uint4 hi = *reinterpret_cast<const uint4 *>(base + (size_t)dy * stride + 4);
+                v[4] = hi.x, v[5] = hi.y, v[6] = hi.z, v[7] = hi.w;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int d = 0; d < SIZE; ++d) best[k] = min(best[k], v[k + d]);
+        }
+        uint8_t *dst = out + ((size_t)s * height + py) * width + q * 4;
+        *reinterpret_cast<uint32_t *>(dst) = (best[0] & 0xFFu) | ((best[1] & 0xFFu) << 8) | ((best[2] & 0xFFu) << 16) | (best[3] << 24);
+    }
+}
+
+// Any size / width.
 __global__ __launch_bounds__(256) void nmi_zbuf_resolve_kernel(const uint32_t *__restrict__ zbuf, uint8_t *__restrict__ out, int views,
-                                                               int width, int height, int size)
+                                                               int width, int height, int size, int stride)
 {
     const int wp = width + size - 1, hp = height + size - 1;
     const int quads = (width + 3) / 4;
@@ -157,10 +216,10 @@ __global__ __launch_bounds__(256) void nmi_zbuf_resolve_kernel(const uint32_t *_
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int q = (int)(i % quads), py = (int)((i / quads) % height), s = (int)(i / ((size_t)quads * height));
         const int px = q * 4;
-        const uint32_t *base = zbuf + (size_t)s * wp * hp + (size_t)py * wp + px;
+        const uint32_t *base = zbuf + ((size_t)s * hp + py) * stride + px;
         uint32_t best[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
         for (int dy = 0; dy < size; ++dy) {
-            const uint32_t *row = base + (size_t)dy * wp;
+            const uint32_t *row = base + (size_t)dy * stride;
             for (int dx = 0; dx < size + 3; ++dx) {
                 if (px + dx >= wp) break;
                 const uint32_t v = row[dx];
@@ -178,7 +237,26 @@ __global__ __launch_bounds__(256) void nmi_zbuf_resolve_kernel(const uint32_t *_
     }
 }
 
-size_t render_zbuf_words(int S, int width, int height, int size) { return (size_t)S * (width + size - 1) * (height + size - 1); }
+static void launch_resolve(const uint32_t *zbuf, uint8_t *out, int S, int width, int height, int size, hipStream_t stream)
+{
+    const int stride = zbuf_stride(width, size);
+    const size_t nq = (size_t)S * height * ((width + 3) / 4);
+    const dim3 grid((unsigned)((nq + 255) / 256 < 8192 ? (nq + 255) / 256 : 8192)), block(256);
+    const bool fast = (width & 3) == 0 && size <= 5 && (((uintptr_t)zbuf & 15) == 0) && (((uintptr_t)out & 3) == 0);
+    if (!fast) {
+        hipLaunchKernelGGL(nmi_zbuf_resolve_kernel, grid, block, 0, stream, zbuf, out, S, width, height, size, stride);
+        return;
+    }
+    switch (size) {
+    case 1: hipLaunchKernelGGL(nmi_zbuf_resolve_fast_kernel<1>, grid, block, 0, stream, zbuf, out, S, width, height, stride); break;
+    case 2: hipLaunchKernelGGL(nmi_zbuf_resolve_fast_kernel<2>, grid, block, 0, stream, zbuf, out, S, width, height, stride); break;
+    case 3: hipLaunchKernelGGL(nmi_zbuf_resolve_fast_kernel<3>, grid, block, 0, stream, zbuf, out, S, width, height, stride); break;
+    case 4: hipLaunchKernelGGL(nmi_zbuf_resolve_fast_kernel<4>, grid, block, 0, stream, zbuf, out, S, width, height, stride); break;
+    default: hipLaunchKernelGGL(nmi_zbuf_resolve_fast_kernel<5>, grid, block, 0, stream, zbuf, out, S, width, height, stride); break;
+    }
+}
+
+size_t render_zbuf_words(int S, int width, int height, int size) { return (size_t)S * zbuf_stride(width, size) * (height + size - 1); }
 
 // ---------------------------------------------------------------------------------------------------------
 // Render-stack producer for textured meshes (nmi_prop_RENDER 1): Rendering<1>::renderToTextureOnGPU,
@@ -343,29 +421,27 @@ hipError_t launch_render_mesh(const float *xyz, const float *uv, long long ntri,
                                mvps + (size_t)s0 * 16, views, zbuf + (size_t)s0 * width * height, width, height, tex);
         }
     }
-    const size_t nq = (size_t)S * height * ((width + 3) / 4);
-    hipLaunchKernelGGL(nmi_zbuf_resolve_kernel, dim3((unsigned)((nq + 255) / 256 < 8192 ? (nq + 255) / 256 : 8192)), dim3(256), 0, stream, zbuf,
-                       out, S, width, height, 1);
+    launch_resolve(zbuf, out, S, width, height, 1, stream);
     return hipGetLastError();
 }
 
 hipError_t launch_render_points(const float *xyz, const float *red, long long npoints, const float *mvps, int S, uint32_t *zbuf,
-                                uint8_t *out, int width, int height, int size, hipStream_t stream)
+                                uint8_t *out, int width, int height, int size, hipStream_t stream, bool clear_first)
 {
     const size_t nz = render_zbuf_words(S, width, height, size);
     const size_t n = (size_t)S * width * height;
-    hipLaunchKernelGGL(nmi_zbuf_clear_kernel, dim3((unsigned)((nz + 255) / 256 < 4096 ? (nz + 255) / 256 : 4096)), dim3(256), 0, stream, zbuf, nz);
+    if (clear_first)
+        hipLaunchKernelGGL(nmi_zbuf_clear_kernel, dim3((unsigned)((nz + 255) / 256 < 4096 ? (nz + 255) / 256 : 4096)), dim3(256), 0, stream, zbuf, nz);
     if (npoints > 0) {
-        const size_t per_view = (size_t)(width + size - 1) * (height + size - 1);
+        const int stride = zbuf_stride(width, size);
+        const size_t per_view = (size_t)stride * (height + size - 1);
         for (int s0 = 0; s0 < S; s0 += kMaxViewsPerLaunch) {
             const int views = S - s0 < kMaxViewsPerLaunch ? S - s0 : kMaxViewsPerLaunch;
             hipLaunchKernelGGL(nmi_splat_kernel, dim3((unsigned)((npoints + 255) / 256)), dim3(256), 0, stream, xyz, red, npoints,
-                               mvps + (size_t)s0 * 16, views, zbuf + (size_t)s0 * per_view, width, height, size);
+                               mvps + (size_t)s0 * 16, views, zbuf + (size_t)s0 * per_view, width, height, size, stride);
         }
     }
-    const size_t nq = (size_t)S * height * ((width + 3) / 4);
-    hipLaunchKernelGGL(nmi_zbuf_resolve_kernel, dim3((unsigned)((nq + 255) / 256 < 8192 ? (nq + 255) / 256 : 8192)), dim3(256), 0, stream, zbuf,
-                       out, S, width, height, size);
+    launch_resolve(zbuf, out, S, width, height, size, stream);
     (void)n;
     return hipGetLastError();
 }

@@ -71,11 +71,13 @@ def test_twin_sanity_single_point():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("point_size", [1.0, 2.0, 3.0, 4.4])
-def test_gpu_splat_bit_exact_vs_twin(point_size):
+@pytest.mark.parametrize("point_size,shape", [(1.0, (160, 120)), (2.0, (160, 120)), (3.0, (160, 120)), (4.4, (160, 120)),
+                                              (5.0, (160, 120)), (7.0, (160, 120)),   # 7: the any-size resolve kernel
+                                              (3.0, (150, 90)), (1.0, (150, 90))])     # width % 4 != 0: likewise
+def test_gpu_splat_bit_exact_vs_twin(point_size, shape):
     torch = pytest.importorskip("torch")
     import orbslam2_nmi_amd as nmi
-    w, h = 160, 120
+    w, h = shape
     xyz, red, rp = plane_cloud(w, h)
     rng = np.random.default_rng(5)
     extra = rng.uniform(-30, 30, (5000, 3)).astype(np.float32)          # clutter at random depths incl. behind / too near / too far
