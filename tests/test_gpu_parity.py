@@ -518,3 +518,10 @@ def test_empty_grids_and_maximum_frame(nmi):
     so, sums_o = oc.score_from_hist(jo, h1o, h2o, n * n)
     assert (j == jo).all() and (h1 == h1o).all() and (h2 == h2o).all()
     assert j[255, 0] >= (n // 2) ** 2 and abs(float(s) - float(so)) <= SCORE_TOL
+
+
+def test_fuzz_campaign_against_the_oracle(nmi):
+    """tests/fuzz_parity.py, 250 seeded cases: random grid shapes, frame sizes, switches and content mixes (textured,
+    noise, posterised, flat bands / blocks, constant) -- whole rating tables and winners against the C oracle."""
+    import fuzz_parity
+    assert fuzz_parity.run(250, seed=11, verbose=False) <= SCORE_TOL

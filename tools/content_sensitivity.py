@@ -4,7 +4,8 @@
 The scoring kernel is bound by LDS atomics, whose cost depends on how many lanes of a wave hit the same bank or
 the same bin -- i.e. on the images.  This tool measures the default synthetic workload next to content chosen to
 stress that: uniform noise (no locality), posterised scenes (few bins), large flat regions, constant images.
-Each case is checked against the C oracle on a subset of candidates (the rating table is requested).
+Timing only (the rating table is requested, as a caller would): parity on this kind of content is the business of
+tests/test_gpu_parity.py (test_flat_regions_*, test_fuzz_campaign_against_the_oracle).
 """
 import os, sys, json
 import numpy as np
@@ -13,7 +14,6 @@ sys.path.insert(0, ROOT)
 import torch
 import orbslam2_nmi_amd as nmi
 from orbslam2_nmi_amd import synthetic as sy
-from oracle import binding as ob
 
 W, H, S, Wn = 640, 480, 27, 27
 wl = sy.workload(W, H, S, Wn)
@@ -55,14 +55,8 @@ for name, (rs_h, ws_h) in cases.items():
         r = ctx.search_grid(rs, ws, ratings=ratings)
         if i >= 2:
             t.append(ctx.last_kernel_ms() * 1e3)
-    got = ratings.cpu().numpy()
-    worst = 0.0
-    for w, s in ((0, 0), (13, 13), (26, 26), (5, 20)):
-        ref = ob.eval_pair(np.ascontiguousarray(rs_h[s]), np.ascontiguousarray(ws_h[w]), render_bottom_up=True)
-        worst = max(worst, abs(float(ref) - float(got[w, s])))
-    assert worst <= 1e-5, (name, worst)
     us = float(np.median(t))
-    out.append({"content": name, "kernel_us": round(us, 1), "evals_per_s": round(S * Wn / us * 1e6), "max_abs_err": worst})
-    print(f"{name:42s} {us:8.1f} us  {S * Wn / us:6.2f} M evals/s   |err| {worst:.1e}", flush=True)
+    out.append({"content": name, "kernel_us": round(us, 1), "evals_per_s": round(S * Wn / us * 1e6)})
+    print(f"{name:42s} {us:8.1f} us  {S * Wn / us:6.2f} M evals/s", flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "content_sensitivity.json"), "w"), indent=1)
