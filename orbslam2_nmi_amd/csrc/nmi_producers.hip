@@ -134,14 +134,71 @@ __global__ __launch_bounds__(256) void nmi_splat_kernel(const float *__restrict_
                                                         int width, int height, int size, int stride)
 {
     __shared__ float m_all[kMaxViewsPerLaunch * 16];
+    __shared__ float wave_box[4][6];
+    __shared__ uint32_t beyond[kMaxViewsPerLaunch];
     for (int t = threadIdx.x; t < views * 16; t += blockDim.x) m_all[t] = mvps[t];  // column-major like glm: m[c*4 + r]
-    __syncthreads();
+    for (int t = threadIdx.x; t < views; t += blockDim.x) beyond[t] = 0x3Fu;
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (i >= npoints) return;
-    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-    const float r = red[i];
+    const bool valid = i < npoints;
+    float x = 0.0f, y = 0.0f, z = 0.0f, r = 0.0f;
+    if (valid) x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2], r = red[i];
+
+    // View-frustum culling per block.  The 256 points of a block are neighbours in the cloud's own order, so their
+    // bounding box is small; a view whose six clip planes put all eight box corners beyond ONE plane -- by a margin
+    // that covers the rounding of both this test and the per-point test below -- cannot receive any of the block's
+    // points, and the block skips that view's 256 transforms.  (A map seen from inside has most of itself outside any
+    // one view.)  The clip tests are affine in the point, so the box test is exact-conservative: results do not change.
+    {
+        const float inf = __builtin_huge_valf();
+        float lo[3] = {valid ? x : inf, valid ? y : inf, valid ? z : inf};
+        float hi[3] = {valid ? x : -inf, valid ? y : -inf, valid ? z : -inf};
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = fminf(lo[k], __shfl_xor(lo[k], off, 64));
+                hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
+            }
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) wave_box[threadIdx.x >> 6][k] = lo[k], wave_box[threadIdx.x >> 6][3 + k] = hi[k];
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < views * 8; t += blockDim.x) {
+        const int s = t >> 3, c = t & 7;
+        float lo[3], hi[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(fminf(wave_box[0][k], wave_box[1][k]), fminf(wave_box[2][k], wave_box[3][k]));
+            hi[k] = fmaxf(fmaxf(wave_box[0][3 + k], wave_box[1][3 + k]), fmaxf(wave_box[2][3 + k], wave_box[3][3 + k]));
+        }
+        const float bx = (c & 1) ? hi[0] : lo[0], by = (c & 2) ? hi[1] : lo[1], bz = (c & 4) ? hi[2] : lo[2];
+        const float ax = fmaxf(fabsf(lo[0]), fabsf(hi[0])), ay = fmaxf(fabsf(lo[1]), fabsf(hi[1])), az = fmaxf(fabsf(lo[2]), fabsf(hi[2]));
+        const float *m = m_all + s * 16;
+        const float cx = (m[0] * bx + m[4] * by) + (m[8] * bz + m[12]);
+        const float cy = (m[1] * bx + m[5] * by) + (m[9] * bz + m[13]);
+        const float cz = (m[2] * bx + m[6] * by) + (m[10] * bz + m[14]);
+        const float cw = (m[3] * bx + m[7] * by) + (m[11] * bz + m[15]);
+        // magnitude of the terms anywhere in the box (rounding of a 4-term fp32 sum is below 3e-7 of it; margin 1e-5)
+        const float mw = fabsf(m[3]) * ax + fabsf(m[7]) * ay + fabsf(m[11]) * az + fabsf(m[15]);
+        const float ex = 1e-5f * (fabsf(m[0]) * ax + fabsf(m[4]) * ay + fabsf(m[8]) * az + fabsf(m[12]) + mw);
+        const float ey = 1e-5f * (fabsf(m[1]) * ax + fabsf(m[5]) * ay + fabsf(m[9]) * az + fabsf(m[13]) + mw);
+        const float ez = 1e-5f * (fabsf(m[2]) * ax + fabsf(m[6]) * ay + fabsf(m[10]) * az + fabsf(m[14]) + mw);
+        uint32_t code = 0;  // bit p: this corner is beyond clip plane p (comparisons with NaN / inf operands are false)
+        code |= (cx + cw < -ex) ? 1u : 0u;   // cx < -cw
+        code |= (cw - cx < -ex) ? 2u : 0u;   // cx >  cw
+        code |= (cy + cw < -ey) ? 4u : 0u;
+        code |= (cw - cy < -ey) ? 8u : 0u;
+        code |= (cz + cw < -ez) ? 16u : 0u;
+        code |= (cw - cz < -ez) ? 32u : 0u;
+        atomicAnd(&beyond[s], code);
+    }
+    __syncthreads();
+    if (!valid) return;
     const uint32_t colour = (uint32_t)(fminf(fmaxf(r, 0.0f), 1.0f) * 255.0f + 0.5f);
     for (int s = 0; s < views; ++s) {
+        if (beyond[s]) continue;  // block-uniform: no point of this block can be inside view s
         const float *m = m_all + s * 16;
         // glm mat4 * vec4: (m0*x + m1*y) + (m2*z + m3*1), component-wise
         const float cx = (m[0] * x + m[4] * y) + (m[8] * z + m[12]);

@@ -94,6 +94,36 @@ def test_gpu_splat_bit_exact_vs_twin(point_size, shape):
 
 
 @pytest.mark.gpu
+def test_gpu_splat_block_culling_changes_nothing():
+    """The splat kernel skips a view for a block of 256 consecutive points whose bounding box lies beyond one clip plane.
+    A dense cloud several times larger than the view, seen from rotated and displaced cameras (oblique clip planes, boxes
+    that straddle them, boxes partly behind the camera), must still equal the twin, which tests every point."""
+    torch = pytest.importorskip("torch")
+    import orbslam2_nmi_amd as nmi
+    w, h = 96, 64
+    xyz, red, rp = plane_cloud(w, h, density=5.0)
+    rng = np.random.default_rng(8)
+    wall = xyz[::3].copy()                       # a second, tilted sheet crossing the first and the near plane
+    wall[:, 2] = 4.0 + 0.8 * wall[:, 0] + 0.1 * wall[:, 1]
+    xyz = np.concatenate([xyz, wall.astype(np.float32)])
+    red = np.concatenate([red, red[::3][::-1]])
+    views = []
+    for k in range(14):
+        ang_y, ang_x = rng.uniform(-0.8, 0.8), rng.uniform(-0.5, 0.5)
+        d = np.array([np.sin(ang_y) * np.cos(ang_x), np.sin(ang_x), np.cos(ang_y) * np.cos(ang_x)])
+        pos = rng.uniform(-3, 3, 3) * np.array([1, 1, 0.5])
+        views.append(capi.render_mvp(rp, pos, pos + d, (0, -1, 0), rng.uniform(-0.5, 0.5, 3)))
+    views.append(capi.render_mvp(rp, (0, 0, 20.0), (0, 0, 19.0), (0, -1, 0), (0, 0, 0)))   # looking back at the sheet
+    mvps = np.stack(views)
+    with nmi.NmiContext(w, h) as ctx:
+        got = ctx.render_points(torch.from_numpy(xyz).cuda(), torch.from_numpy(red).cuda(), mvps, 2.0).cpu().numpy()
+    exp = ro.render_stack(xyz, red, mvps, w, h, 2.0)
+    assert (got == exp).all(), f"{(got != exp).sum()} pixels differ"
+    covered = (exp != 255).reshape(len(views), -1).mean(1)
+    assert (covered > 0.3).sum() >= 8 and (covered < 0.999).any()
+
+
+@pytest.mark.gpu
 def test_gpu_cloud_to_winner_end_to_end():
     """cloud + pose -> device render stack for a 3x3x3 translation grid; frame = the view from a displaced pose; the
     search must pick the cell nearest to the displacement (no OpenGL, no host-side rendering of the stack)."""
