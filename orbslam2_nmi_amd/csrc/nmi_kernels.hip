@@ -624,6 +624,27 @@ __device__ __forceinline__ void exact_candidate(Lds &lds, const GridArgs &a, int
     __syncthreads();
 }
 
+// Completion, called by lane 0 of each workgroup when it has scored its last candidate: the last workgroup to finish
+// publishes the winner.  Every atomicMax of final_phase and the counter below are device-scope read-modify-writes
+// performed at the memory side.  The counter increment carries a data dependency on the values returned by this
+// workgroup's maxes, so it is issued after they were performed; the workgroup that draws the last ticket therefore
+// reads the final key.  Nothing here needs a cache write-back: the key travels in atomics, and the mailbox is one
+// 8-byte store (key in bits 0..62, launch parity in bit 63 -- scores are non-negative floats, bit 63 is free).
+__device__ __forceinline__ void publish_winner(const GridArgs &a, unsigned long long prev_key)
+{
+    const unsigned int one = prev_key == ~0ull ? 2u : 1u;  // always 1 (a key never has all bits set)
+    const unsigned int arrived = __hip_atomic_fetch_add(a.done, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (arrived == gridDim.x - 1) {
+        const unsigned long long final_key = __hip_atomic_load(a.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.out_key)  // may be pinned host memory that a caller polls (nmi_level_run)
+            __hip_atomic_store(a.out_key, final_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (a.mailbox)
+            __hip_atomic_store(&a.mailbox->word, final_key | ((unsigned long long)(a.seq & 1u) << 63), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 }  // namespace
 
 // One workgroup per candidate (grid-stride over the candidates of this launch).
@@ -724,25 +745,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
         for (int o = exact_from; o < total; o += gridDim.x) exact_candidate<SHIFTED>(lds, a, tid, candidate_at(a, o), prev_key);
     }
 
-    // ---- completion: the last workgroup to finish publishes the winner -------------------------------------
-    // Every atomicMax above and the counter below are device-scope read-modify-writes performed at the memory
-    // side.  The counter increment carries a data dependency on the values returned by this workgroup's maxes,
-    // so it is issued after they were performed; the workgroup that draws the last ticket therefore reads the
-    // final key.  Nothing here needs a cache write-back: the key travels in atomics, and the mailbox is one
-    // 8-byte store (key in bits 0..62, launch parity in bit 63 -- scores are non-negative floats, bit 63 is free).
-    if (tid == 0 && !(a.phase_mask & 16)) {  // bit 4: timing experiment without the completion protocol (no result)
-        const unsigned int one = prev_key == ~0ull ? 2u : 1u;  // always 1 (a key never has all bits set)
-        const unsigned int arrived = __hip_atomic_fetch_add(a.done, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (arrived == gridDim.x - 1) {
-            const unsigned long long final_key = __hip_atomic_load(a.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a.out_key)  // may be pinned host memory that a caller polls (nmi_level_run)
-                __hip_atomic_store(a.out_key, final_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (a.mailbox)
-                __hip_atomic_store(&a.mailbox->word, final_key | ((unsigned long long)(a.seq & 1u) << 63), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    if (tid == 0 && !(a.phase_mask & 16)) publish_winner(a, prev_key);  // bit 4: timing experiment without the protocol (no result)
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -954,20 +957,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel_ws(GridArgs
         for (int kk = kd + 1; kk < n; ++kk) exact_candidate<SHIFTED>(lds, a, tid, candidate_at(a, slot + kk * (int)gridDim.x), prev_key);
     }
 
-    // completion: identical to the sequential kernel
-    if (tid == 0) {
-        const unsigned int one = prev_key == ~0ull ? 2u : 1u;
-        const unsigned int arrived = __hip_atomic_fetch_add(a.done, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (arrived == gridDim.x - 1) {
-            const unsigned long long final_key = __hip_atomic_load(a.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a.out_key)  // may be pinned host memory that a caller polls (nmi_level_run)
-                __hip_atomic_store(a.out_key, final_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (a.mailbox)
-                __hip_atomic_store(&a.mailbox->word, final_key | ((unsigned long long)(a.seq & 1u) << 63), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    if (tid == 0) publish_winner(a, prev_key);
 }
 
 // table[c] = (c/len) * log2(c/len) in the reference's fp32 form (NMI.cu:245): p = fl32(c/len),
