@@ -183,11 +183,13 @@ int nmi_render_mesh(nmi_ctx *ctx, const float *d_xyz, const float *d_uv, int64_t
 
 /*
  * One whole search level on the device as a captured HIP graph: S renders of the cloud (nmi_render_points), Wn warps of the
- * frame (nmi_warp_stack), the S x Wn search (nmi_search_grid) and the winner's copy to the host replay with a single
- * hipGraphLaunch.  Create once per (cloud, frame, S, Wn); nmi_level_run takes this level's S view matrices
- * (nmi_render_mvp, float[S][16]) and Wn forward homographies (nmi_warp_homographies, double[Wn][9]) and blocks for the
- * winner.  Same results as the three calls made one after the other.  The device pointers given at creation must stay
- * valid and unchanged in place (their contents may change between runs).
+ * frame (nmi_warp_stack) and the S x Wn search (nmi_search_grid) replay with a single hipGraphLaunch -- five kernel nodes
+ * (parameter fetch + clear, splat, resolve, warp on a forked branch, search), no copy nodes.  Create once per (cloud, frame,
+ * S, Wn); nmi_level_run takes this level's S view matrices (nmi_render_mvp, float[S][16]) and Wn forward homographies
+ * (nmi_warp_homographies, double[Wn][9]) and blocks until the search has posted its winner to pinned host memory (the
+ * context's stream drains a few microseconds later; work enqueued on it afterwards is ordered as usual).  Same results as
+ * the three calls made one after the other.  The device pointers given at creation must stay valid and unchanged in
+ * place (their contents may change between runs).
  */
 typedef struct nmi_level nmi_level;
 int nmi_level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int64_t n_points, const uint8_t *d_frame, int32_t S,
