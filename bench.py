@@ -144,8 +144,7 @@ def run_e2e_config(args):
     dx, dr = torch.from_numpy(xyz).cuda(), torch.from_numpy(red).cuda()
     ctx = nmi.NmiContext(w, h)
     ctx.set_stream(stream.cuda_stream)
-    Twc = np.eye(4, dtype=np.float32)
-    Twc[:3, 1] = [0, -1, 0]
+    Twc = np.eye(4, dtype=np.float32)  # ORB-SLAM camera axes: x right, y down, z forward (setupCam, ioData.cpp:177-197)
     pos, look, up = Twc[:3, 3], Twc[:3, 3] + Twc[:3, 2], Twc[:3, 1]
     grids = [H.SearchKernel.make([3] * 6, [s / 2 ** l for s in (0.2, 0.2, 0.5, 0.02, 0.02, 0.05)]) for l in range(levels)]
     cells = [(sx, sy, sz) for sz in range(3) for sy in range(3) for sx in range(3)]

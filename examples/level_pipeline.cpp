@@ -1,0 +1,207 @@
+// level_pipeline.cpp -- C++ host program: keyframe refinement with EVERYTHING on the device.
+//
+// The map is a coloured point cloud in HBM (nmi_prop_RENDER 4), the camera frame is in HBM; per iteration of
+// Tracking::RelocalizeWithNMIStrategy (Tracking.cc:1987-2179, here nmi_relocalize_with_strategy) the host computes 27 view
+// matrices (Rendering::calculateTranslationCV + the MVP of rendering.hpp:196-202) and 27 homographies (image.cpp:76-107)
+// and replays ONE captured HIP graph (nmi_level_run): renders, warps, the 729-candidate search, winner back.  Only
+// matrices and the 8-byte winner cross PCIe.  Prints what was recovered and the rate in keyframes/s and levels/s --
+// the native counterpart of `bench.py --config e2e`, without the Python between two levels.
+// Exit code 0 iff the planted camera offset is recovered (lateral offset as seen in the image within 8 cm, depth within 20 cm).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "nmi_hip.h"
+#include "nmi_host.h"
+#include "nmi_search_kernel.hpp"
+
+#define CHECK_HIP(x)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (x);                                                               \
+        if (e_ != hipSuccess) {                                                            \
+            fprintf(stderr, "%s failed: %s\n", #x, hipGetErrorString(e_));                 \
+            return 2;                                                                      \
+        }                                                                                  \
+    } while (0)
+#define CHECK_NMI(x)                                                                       \
+    do {                                                                                   \
+        int r_ = (x);                                                                      \
+        if (r_ != NMI_OK) {                                                                \
+            fprintf(stderr, "%s failed: %d (%s)\n", #x, r_, nmi_error_string(r_));         \
+            return 2;                                                                      \
+        }                                                                                  \
+    } while (0)
+
+namespace {
+
+constexpr int W = 848, H = 480;  // Newer-College-shaped frames (BASELINE.json configs[3])
+// Examples/Monocular/ETH_small.yaml:8-11 calibration (960x540) scaled to the frame
+constexpr double FX = 435.04593205 * W / 960.0, FY = 435.04593205 * H / 540.0, CX = 475.55781765 * W / 960.0, CY = 274.7487729 * H / 540.0;
+constexpr float DEPTH = 10.0f;
+
+struct Pipeline {
+    nmi_level *level = nullptr;
+    nmi_render_params rp{};
+    int levels_run = 0;
+};
+
+// Replacement for the body of Tracking::RelocalizeWithNMI (Tracking.cc:1871-1905) with the producers on the device.
+int eval_level(void *user, const nmi_search_kernel *g, const float Twc[16], int64_t *best_index, float *best_score)
+{
+    Pipeline &p = *static_cast<Pipeline *>(user);
+    if (g->num[0] != 3 || g->num[1] != 3 || g->num[2] != 3 || g->num[3] != 3 || g->num[4] != 3 || g->num[5] != 3) return -20;
+    // setupCam (ioData.cpp:177-197): position, a point ahead, the up vector, from the columns of Twc
+    const float pos[3] = {Twc[3], Twc[7], Twc[11]};
+    const float look[3] = {pos[0] + Twc[2], pos[1] + Twc[6], pos[2] + Twc[10]};
+    const float up[3] = {Twc[1], Twc[5], Twc[9]};
+    float mvps[27 * 16];
+    for (int sz = 0; sz < 3; ++sz)
+        for (int sy = 0; sy < 3; ++sy)
+            for (int sx = 0; sx < 3; ++sx) {
+                float t[3];
+                int rc = nmi_calculate_translation(Twc, g, sx, sy, sz, t);
+                if (rc != NMI_OK) return rc;
+                if ((rc = nmi_render_mvp(&p.rp, pos, look, up, t, mvps + 16 * ((sz * 3 + sy) * 3 + sx))) != NMI_OK) return rc;
+            }
+    const double K[9] = {FX, 0, CX, 0, FY, CY, 0, 0, 1};
+    const int32_t nw[3] = {3, 3, 3};
+    const float sw[3] = {g->step[3], g->step[4], g->step[5]};
+    double M[27 * 9];
+    int rc = nmi_warp_homographies(K, nw, sw, M);
+    if (rc != NMI_OK) return rc;
+    ++p.levels_run;
+    return nmi_level_run(p.level, mvps, M, best_index, best_score);
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    const int keyframes = argc > 1 ? atoi(argv[1]) : 200;
+    nmi_params prm;
+    CHECK_NMI(nmi_params_default(&prm, W, H));
+    nmi_ctx *ctx = nullptr;
+    CHECK_NMI(nmi_create(&prm, &ctx));
+
+    // The map: a textured, undulating surface about 10 m ahead, three frame-widths wide, ~0.8 points per pixel of a view
+    // (3 M points).
+    const int nu = (int)(3 * W * 0.9), nv = (int)(3 * H * 0.9);
+    std::vector<float> xyz((size_t)nu * nv * 3), red((size_t)nu * nv);
+    unsigned s = 2468u;
+    for (int j = 0; j < nv; ++j)
+        for (int i = 0; i < nu; ++i) {
+            const float u = -W + 3.0f * W * i / (nu - 1), v = -H + 3.0f * H * j / (nv - 1);
+            const size_t k = (size_t)j * nu + i;
+            // relief of +-3 m: on a flat wall a sideways step and a small turn of the camera move the image alike, and
+            // the 6-D search could not tell them apart
+            const float z = DEPTH + 3.0f * sinf(0.012f * u) * cosf(0.015f * v);
+            xyz[3 * k] = (u - (float)CX) / (float)FX * z;
+            xyz[3 * k + 1] = (v - (float)CY) / (float)FY * z;
+            xyz[3 * k + 2] = z;
+            s = s * 1664525u + 1013904223u;
+            const float n = ((s >> 8) & 0xFFFF) / 65535.0f - 0.5f;
+            const float t = 128.0f + 45.0f * sinf(0.031f * u + 0.6f * sinf(0.017f * v)) + 40.0f * cosf(0.043f * v + 0.011f * u) +
+                            18.0f * sinf(0.11f * (u + v)) + 10.0f * n;
+            red[k] = fminf(fmaxf(t, 0.0f), 255.0f) / 256.0f;  // objloader.cpp:261: colour / 256
+        }
+    float *d_xyz = nullptr, *d_red = nullptr;
+    uint8_t *d_frame = nullptr, *d_tmp = nullptr;
+    CHECK_HIP(hipMalloc((void **)&d_xyz, xyz.size() * sizeof(float)));
+    CHECK_HIP(hipMalloc((void **)&d_red, red.size() * sizeof(float)));
+    CHECK_HIP(hipMalloc((void **)&d_frame, (size_t)W * H));
+    CHECK_HIP(hipMalloc((void **)&d_tmp, (size_t)W * H));
+    CHECK_HIP(hipMemcpy(d_xyz, xyz.data(), xyz.size() * sizeof(float), hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(d_red, red.data(), red.size() * sizeof(float), hipMemcpyHostToDevice));
+
+    Pipeline p;
+    p.rp = nmi_render_params{FX, FY, CX, CY, 5.0f, 30.0f, 3.0f};
+
+    // The tracker's pose: camera at the origin, ORB-SLAM axes (x right, y down, z forward) = world axes.
+    float Twc0[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    // The frame was taken from a pose displaced by `truth` (world metres): render it there, turn it top-down, add sensor noise.
+    const float truth[3] = {0.25f, -0.15f, 0.40f};
+    {
+        const float pos[3] = {truth[0], truth[1], truth[2]};
+        const float look[3] = {pos[0] + Twc0[2], pos[1] + Twc0[6], pos[2] + Twc0[10]};
+        const float up[3] = {Twc0[1], Twc0[5], Twc0[9]};
+        const float zero[3] = {0, 0, 0};
+        float mvp[16];
+        CHECK_NMI(nmi_render_mvp(&p.rp, pos, look, up, zero, mvp));
+        CHECK_NMI(nmi_render_points(ctx, d_xyz, d_red, (int64_t)red.size(), mvp, 1, p.rp.point_size, d_tmp));
+        CHECK_NMI(nmi_synchronize(ctx));
+        std::vector<uint8_t> img((size_t)W * H), frame((size_t)W * H);
+        CHECK_HIP(hipMemcpy(img.data(), d_tmp, img.size(), hipMemcpyDeviceToHost));
+        unsigned q = 97531u;
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                float acc = 0.0f;  // sum of 4 uniforms: bell-shaped noise, sigma ~ 9 grey levels
+                for (int k = 0; k < 4; ++k) {
+                    q = q * 1664525u + 1013904223u;
+                    acc += ((q >> 8) & 0xFFFF) / 65535.0f - 0.5f;
+                }
+                const float val = (float)img[(size_t)(H - 1 - y) * W + x] + 16.0f * acc;
+                frame[(size_t)y * W + x] = (uint8_t)lrintf(fminf(fmaxf(val, 0.0f), 255.0f));
+            }
+        CHECK_HIP(hipMemcpy(d_frame, frame.data(), frame.size(), hipMemcpyHostToDevice));
+    }
+    CHECK_NMI(nmi_level_create(ctx, d_xyz, d_red, (int64_t)red.size(), d_frame, 27, 27, p.rp.point_size, &p.level));
+
+    // 3^6 grid with the steps of ETH_small.yaml:83-88
+    NmiSearchKernel initial(3, 3, 3, 3, 3, 3, 0.2f, 0.2f, 0.5f, 0.02f, 0.02f, 0.05f);
+    nmi_strategy_input in;
+    memset(&in, 0, sizeof in);
+    CHECK_NMI(nmi_mat4_inverse(Twc0, in.Tcw));
+    in.nmi_threshold = 0.05f;
+    in.initial = initial.to_c();
+    nmi_properties props;
+    nmi_properties_default(&props);
+    nmi_strategy_output out;
+
+    CHECK_NMI(nmi_relocalize_with_strategy(&in, &props, eval_level, &p, &out));  // warm-up + the checked run
+    float Twc[16];
+    CHECK_NMI(nmi_mat4_inverse(out.Tcw, Twc));
+    for (int i = 0; i < out.iterations; ++i) {
+        char line[256];
+        nmi_sk_format(&out.per_iteration[i], line, sizeof line);
+        printf("NmiKernel:\t%s\n", line);
+    }
+    printf("relocalized=%d failed=%d iterations=%d stop=%d  recovered t = (%.3f, %.3f, %.3f)  truth (%.3f, %.3f, %.3f)  NMI %.5f\n",
+           out.relocalized, out.failed, out.iterations, out.stop_reason, Twc[3], Twc[7], Twc[11], truth[0], truth[1], truth[2],
+           out.kernel.nmi);
+    printf("recovered camera axes: x (%.4f %.4f %.4f)  y (%.4f %.4f %.4f)  z (%.4f %.4f %.4f)\n", Twc[0], Twc[4], Twc[8], Twc[1], Twc[5],
+           Twc[9], Twc[2], Twc[6], Twc[10]);
+    // At ~10 m a sideways step t and a turn by t / 10 m move the image almost alike (the relief separates them only
+    // weakly), and the search is free to mix them: judge the lateral result by their sum, the offset an observer of the
+    // image would infer.  The recovered optical axis is the third column of Twc.
+    const float ex = Twc[3] + DEPTH * Twc[2], ey = Twc[7] + DEPTH * Twc[6];
+    printf("lateral offset seen in the image: (%.3f, %.3f) m, truth (%.3f, %.3f)\n", ex, ey, truth[0], truth[1]);
+    bool ok = out.relocalized && !out.failed && out.iterations >= 2;
+    ok = ok && fabsf(ex - truth[0]) <= 0.08f && fabsf(ey - truth[1]) <= 0.08f && fabsf(Twc[11] - truth[2]) <= 0.2f;
+    ok = ok && out.kernel.nmi > out.per_iteration[0].nmi;  // refinement improved the score
+
+    p.levels_run = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < keyframes; ++k) {
+        nmi_strategy_output o;
+        CHECK_NMI(nmi_relocalize_with_strategy(&in, &props, eval_level, &p, &o));
+        ok = ok && o.kernel.best[0] == out.kernel.best[0] && o.kernel.nmi == out.kernel.nmi;  // deterministic
+    }
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    printf("%d keyframes, %d levels (27 renders of %zu points + 27 warps + 729-candidate search each): %.1f keyframes/s, %.1f levels/s, "
+           "%.3f ms per level\n",
+           keyframes, p.levels_run, red.size(), keyframes / dt, p.levels_run / dt, dt / p.levels_run * 1e3);
+
+    nmi_level_destroy(p.level);
+    (void)hipFree(d_xyz);
+    (void)hipFree(d_red);
+    (void)hipFree(d_frame);
+    (void)hipFree(d_tmp);
+    nmi_destroy(ctx);
+    printf("%s\n", ok ? "PIPELINE OK" : "PIPELINE FAILED");
+    return ok ? 0 : 1;
+}

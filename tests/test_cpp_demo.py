@@ -1,5 +1,6 @@
-"""The C++ host program on the drop-in boundary (examples/relocalize_demo.cpp): reference-style classes + C ABI + shim,
-no Python in the loop.  CPU tier: it builds and links.  GPU tier: it recovers a planted pose offset."""
+"""The C++ host programs on the drop-in boundary, no Python in the loop: examples/relocalize_demo.cpp (reference-style
+classes + C ABI + shim, toy host renderer) and examples/level_pipeline.cpp (renders, warps and search on the device, one
+HIP graph per strategy iteration).  CPU tier: they build and link.  GPU tier: each recovers a planted pose offset."""
 import os
 import subprocess
 
@@ -8,13 +9,14 @@ import pytest
 from conftest import ROOT
 
 EXE = os.path.join(ROOT, "examples", "relocalize_demo")
+EXE_PIPELINE = os.path.join(ROOT, "examples", "level_pipeline")
 
 
 def test_demo_builds():
     from orbslam2_nmi_amd import build as nmi_build
     nmi_build.build()
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    assert os.access(EXE, os.X_OK)
+    assert os.access(EXE, os.X_OK) and os.access(EXE_PIPELINE, os.X_OK)
 
 
 @pytest.mark.gpu
@@ -25,3 +27,13 @@ def test_demo_recovers_planted_offset():
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "DEMO OK" in r.stdout and "NmiKernel:" in r.stdout
+
+
+@pytest.mark.gpu
+def test_device_pipeline_recovers_planted_offset():
+    if not os.access(EXE_PIPELINE, os.X_OK):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    r = subprocess.run([EXE_PIPELINE, "20"], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "PIPELINE OK" in r.stdout and "levels/s" in r.stdout
