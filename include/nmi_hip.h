@@ -254,6 +254,9 @@ int nmi_last_kernel_ms(nmi_ctx *ctx, float *h_ms);
                                   and the call polls it (default), 0 hipMemcpyAsync + hipStreamSynchronize */
 #define NMI_OPT_XCD_TILING 5   /* 1 (default): candidates are visited in (warp x render) tiles so that the 32 workgroups
                                   of one XCD share ~12 images in its L2; 0: linear order.  Same results either way. */
+#define NMI_OPT_TILE_QUEUE 6   /* mesh renderer: capacity (work items) of the queue that hands large triangles to the
+                                  tile pass, at most 4194304 (default); 0 = every triangle is shaded by its own lane.
+                                  Same image for every value (small values exercise the overflow path in tests). */
 int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value);
 
 /* Introspection. */

@@ -227,7 +227,7 @@ class NmiContext:
         if getattr(self, "_bound_stream", None) != cur.cuda_stream:
             cur.synchronize()
 
-    OPT_HIST_VARIANT, OPT_PHASE_MASK, OPT_WORKGROUPS, OPT_RESULT_PATH, OPT_XCD_TILING = 1, 2, 3, 4, 5
+    OPT_HIST_VARIANT, OPT_PHASE_MASK, OPT_WORKGROUPS, OPT_RESULT_PATH, OPT_XCD_TILING, OPT_TILE_QUEUE = 1, 2, 3, 4, 5, 6
 
     def set_option(self, option, value):
         self._check(self._lib.nmi_set_option(self._h, int(option), int(value)), "nmi_set_option")

@@ -242,11 +242,21 @@ int nmi_render_mesh(nmi_ctx *ctx, const float *d_xyz, const float *d_uv, int64_t
         NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_zbuf, (size_t)need * sizeof(uint32_t)));
         ctx->zbuf_cap = need;
     }
+    if (!ctx->d_tile_queue) {
+        // Work queue of the large-triangle pass: 4 M (triangle, view, 64x64 tile) items = 32 MiB.  Meshes that need more
+        // (the lanes of the first pass then shade the excess themselves) are far beyond a map of textured facades.
+        constexpr unsigned long long kItems = 4ull << 20;
+        NMI_HIP_TRY(ctx, hipMalloc(&ctx->d_tile_queue, (size_t)kItems * nmi::mesh_tile_item_bytes()));
+        ctx->tile_queue_cap = kItems;
+        NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tile_state, 2 * sizeof(unsigned long long)));
+    }
     float *d_mvps = nullptr;
     int rc = stage_floats(ctx, ctx->mvp_ring, h_mvps, (size_t)S * 16, &d_mvps);
     if (rc != NMI_OK) return rc;
     NMI_HIP_TRY(ctx, nmi::launch_render_mesh(d_xyz, d_uv, n_triangles, tex->d_luma, tex->levels, tex->w, tex->h, tex->off, d_mvps, S,
-                                             ctx->d_zbuf, d_render_stack, ctx->params.width, ctx->params.height, ctx->stream));
+                                             ctx->d_zbuf, d_render_stack, ctx->params.width, ctx->params.height, ctx->d_tile_queue,
+                                             ctx->tile_queue_limit < ctx->tile_queue_cap ? ctx->tile_queue_limit : ctx->tile_queue_cap,
+                                             ctx->d_tile_state, ctx->stream));
     return NMI_OK;
 }
 

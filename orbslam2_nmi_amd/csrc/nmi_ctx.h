@@ -53,6 +53,10 @@ struct nmi_ctx {
     int xcd_tiling = 1;                   // NMI_OPT_XCD_TILING
     uint32_t *d_zbuf = nullptr;           // depth|colour anchor buffers of the point-cloud renderer (padded, per view)
     int64_t zbuf_cap = 0;
+    void *d_tile_queue = nullptr;          // mesh renderer: (triangle, view, tile) work items of large triangles
+    unsigned long long tile_queue_cap = 0;      // allocated items
+    unsigned long long tile_queue_limit = 4ull << 20;  // NMI_OPT_TILE_QUEUE
+    unsigned long long *d_tile_state = nullptr;  // [2] claimed / ~(first claim that did not fit)
     StagingRing mvp_ring;
     uint32_t *d_scratch = nullptr;        // drained-counter slabs of the pipelined kernel
     int scratch_workgroups = 0;

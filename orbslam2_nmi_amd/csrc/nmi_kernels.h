@@ -68,9 +68,13 @@ size_t grid_kernel_scratch_bytes(int workgroups);
 hipError_t launch_warp(const uint8_t *frame, const float *coeffs /*[Wn][9] inverse maps*/, uint8_t *out, int width,
                        int height, int Wn, hipStream_t stream);
 
+// tile_queue: device memory for tile_queue_cap work items of mesh_tile_item_bytes() each (large triangles are shaded by
+// a second kernel, one wavefront per 64x64 tile); queue_state: two device words; either may be null (everything in-lane).
 hipError_t launch_render_mesh(const float *xyz, const float *uv, long long ntri, const float *luma, int levels, const int *lw,
                               const int *lh, const long long *loff, const float *mvps /*[S][16]*/, int S, uint32_t *zbuf /*[S][H][W]*/,
-                              uint8_t *out, int width, int height, hipStream_t stream);
+                              uint8_t *out, int width, int height, void *tile_queue, unsigned long long tile_queue_cap,
+                              unsigned long long *queue_state, hipStream_t stream, bool clear_first = true);
+size_t mesh_tile_item_bytes();
 // Words between rows of the renderers' anchor / depth buffer: the padded width, rounded so that the resolve pass can
 // read 8 consecutive anchors of any output quad with two aligned 16-byte loads (point sizes > 1); width for size 1.
 inline int zbuf_stride(int width, int size) { return size > 1 ? ((width + size - 1 + 3) & ~3) + 4 : width; }

@@ -125,49 +125,32 @@ hipError_t launch_level_prep(const float *h_mvps, float *d_mvps, int n_mvps, con
     return hipGetLastError();
 }
 
-// One lane per point, looping over the S views: the cloud is read once, not once per view (27 views of a 3 M-point
-// cloud would otherwise stream 1.3 GB per level); the S matrices sit in LDS.
-constexpr int kMaxViewsPerLaunch = 64;
-
-__global__ __launch_bounds__(256) void nmi_splat_kernel(const float *__restrict__ xyz, const float *__restrict__ red, long long npoints,
-                                                        const float *__restrict__ mvps, int views, uint32_t *__restrict__ zbuf,
-                                                        int width, int height, int size, int stride)
+// View-frustum culling per block of 256 lanes.  Each lane brings the bounding box of its own primitive (a point, the
+// three corners of a triangle; +inf / -inf for a lane without one); the primitives of a block are neighbours in the
+// map's own order, so their common box is small.  A view whose clip planes put all eight corners of that box beyond ONE
+// plane -- by a margin that covers the rounding of both this test and the per-primitive test that follows -- cannot
+// receive anything from the block, which then skips that view's 256 transforms.  (A map seen from inside has most of
+// itself outside any one view.)  The clip tests are affine in the position, so the box test is exact-conservative:
+// results do not change.  On return (after a barrier) beyond[s] != 0 means "skip view s".  m_all must be loaded and
+// beyond[s] preset to 0x3F by the caller, both before its own barrier... which this function provides.
+__device__ __forceinline__ void block_frustum_cull(const float *m_all, int views, const float (&lo_in)[3], const float (&hi_in)[3],
+                                                   float (*wave_box)[6], uint32_t *beyond)
 {
-    __shared__ float m_all[kMaxViewsPerLaunch * 16];
-    __shared__ float wave_box[4][6];
-    __shared__ uint32_t beyond[kMaxViewsPerLaunch];
-    for (int t = threadIdx.x; t < views * 16; t += blockDim.x) m_all[t] = mvps[t];  // column-major like glm: m[c*4 + r]
-    for (int t = threadIdx.x; t < views; t += blockDim.x) beyond[t] = 0x3Fu;
-    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    const bool valid = i < npoints;
-    float x = 0.0f, y = 0.0f, z = 0.0f, r = 0.0f;
-    if (valid) x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2], r = red[i];
-
-    // View-frustum culling per block.  The 256 points of a block are neighbours in the cloud's own order, so their
-    // bounding box is small; a view whose six clip planes put all eight box corners beyond ONE plane -- by a margin
-    // that covers the rounding of both this test and the per-point test below -- cannot receive any of the block's
-    // points, and the block skips that view's 256 transforms.  (A map seen from inside has most of itself outside any
-    // one view.)  The clip tests are affine in the point, so the box test is exact-conservative: results do not change.
-    {
-        const float inf = __builtin_huge_valf();
-        float lo[3] = {valid ? x : inf, valid ? y : inf, valid ? z : inf};
-        float hi[3] = {valid ? x : -inf, valid ? y : -inf, valid ? z : -inf};
+    float lo[3] = {lo_in[0], lo_in[1], lo_in[2]}, hi[3] = {hi_in[0], hi_in[1], hi_in[2]};
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
+    for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                lo[k] = fminf(lo[k], __shfl_xor(lo[k], off, 64));
-                hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
-            }
-        if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) wave_box[threadIdx.x >> 6][k] = lo[k], wave_box[threadIdx.x >> 6][3 + k] = hi[k];
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off, 64));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
         }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wave_box[threadIdx.x >> 6][k] = lo[k], wave_box[threadIdx.x >> 6][3 + k] = hi[k];
     }
     __syncthreads();
     for (int t = threadIdx.x; t < views * 8; t += blockDim.x) {
         const int s = t >> 3, c = t & 7;
-        float lo[3], hi[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             lo[k] = fminf(fminf(wave_box[0][k], wave_box[1][k]), fminf(wave_box[2][k], wave_box[3][k]));
@@ -195,6 +178,32 @@ __global__ __launch_bounds__(256) void nmi_splat_kernel(const float *__restrict_
         atomicAnd(&beyond[s], code);
     }
     __syncthreads();
+}
+
+// One lane per point, looping over the S views: the cloud is read once, not once per view (27 views of a 3 M-point
+// cloud would otherwise stream 1.3 GB per level); the S matrices sit in LDS.
+constexpr int kMaxViewsPerLaunch = 64;
+
+__global__ __launch_bounds__(256) void nmi_splat_kernel(const float *__restrict__ xyz, const float *__restrict__ red, long long npoints,
+                                                        const float *__restrict__ mvps, int views, uint32_t *__restrict__ zbuf,
+                                                        int width, int height, int size, int stride)
+{
+    __shared__ float m_all[kMaxViewsPerLaunch * 16];
+    __shared__ float wave_box[4][6];
+    __shared__ uint32_t beyond[kMaxViewsPerLaunch];
+    for (int t = threadIdx.x; t < views * 16; t += blockDim.x) m_all[t] = mvps[t];  // column-major like glm: m[c*4 + r]
+    for (int t = threadIdx.x; t < views; t += blockDim.x) beyond[t] = 0x3Fu;
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const bool valid = i < npoints;
+    float x = 0.0f, y = 0.0f, z = 0.0f, r = 0.0f;
+    if (valid) x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2], r = red[i];
+
+    {
+        const float inf = __builtin_huge_valf();
+        const float lo[3] = {valid ? x : inf, valid ? y : inf, valid ? z : inf};
+        const float hi[3] = {valid ? x : -inf, valid ? y : -inf, valid ? z : -inf};
+        block_frustum_cull(m_all, views, lo, hi, wave_box, beyond);
+    }
     if (!valid) return;
     const uint32_t colour = (uint32_t)(fminf(fmaxf(r, 0.0f), 1.0f) * 255.0f + 0.5f);
     for (int s = 0; s < views; ++s) {
@@ -356,131 +365,247 @@ __device__ __forceinline__ bool edge_owner(float ex, float ey)
     return ey < 0.0f || (ey == 0.0f && ex < 0.0f);
 }
 
-__global__ __launch_bounds__(256) void nmi_mesh_kernel(const float *__restrict__ xyz, const float *__restrict__ uv, long long ntri,
-                                                       const float *__restrict__ mvps, int views, uint32_t *__restrict__ zbuf,
-                                                       int width, int height, MeshTexture tex)
+// One triangle seen by one view: everything the per-pixel work needs.  Both kernels below build it with the same
+// arithmetic, so which of them shades a pixel does not change its value.
+struct TriView {
+    float xw[3], yw[3], zw[3], iw[3];  // window x, y, depth, 1/w of the corners
+    float ex[3], ey[3];                // edge k is opposite vertex k: from vertex (k+1)%3 to vertex (k+2)%3
+    bool own[3];
+    float inv_area;
+    int x_lo, x_hi, y_lo, y_hi;        // pixel bounding box, clamped to the window
+};
+
+__device__ __forceinline__ bool tri_setup(const float *__restrict__ m, const float (&px)[3], const float (&py)[3], const float (&pz)[3],
+                                          int width, int height, TriView &t)
 {
-    __shared__ float m_all[kMaxViewsPerLaunch * 16];
-    for (int t = threadIdx.x; t < views * 16; t += blockDim.x) m_all[t] = mvps[t];
-    __syncthreads();
-    const long long tri = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (tri >= ntri) return;
-    float px[3], py[3], pz[3], tu[3], tv[3];
+    float cx[3], cy[3], cz[3], cw[3];
+    bool behind = false;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        px[k] = xyz[(tri * 3 + k) * 3], py[k] = xyz[(tri * 3 + k) * 3 + 1], pz[k] = xyz[(tri * 3 + k) * 3 + 2];
-        tu[k] = uv[(tri * 3 + k) * 2], tv[k] = uv[(tri * 3 + k) * 2 + 1];
+        cx[k] = (m[0] * px[k] + m[4] * py[k]) + (m[8] * pz[k] + m[12]);
+        cy[k] = (m[1] * px[k] + m[5] * py[k]) + (m[9] * pz[k] + m[13]);
+        cz[k] = (m[2] * px[k] + m[6] * py[k]) + (m[10] * pz[k] + m[14]);
+        cw[k] = (m[3] * px[k] + m[7] * py[k]) + (m[11] * pz[k] + m[15]);
+        behind = behind || !(cw[k] > 0.0f);
     }
+    if (behind) return false;
+    if ((cx[0] < -cw[0] && cx[1] < -cw[1] && cx[2] < -cw[2]) || (cx[0] > cw[0] && cx[1] > cw[1] && cx[2] > cw[2]) ||
+        (cy[0] < -cw[0] && cy[1] < -cw[1] && cy[2] < -cw[2]) || (cy[0] > cw[0] && cy[1] > cw[1] && cy[2] > cw[2]) ||
+        (cz[0] < -cw[0] && cz[1] < -cw[1] && cz[2] < -cw[2]) || (cz[0] > cw[0] && cz[1] > cw[1] && cz[2] > cw[2]))
+        return false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        t.xw[k] = (cx[k] / cw[k] * 0.5f + 0.5f) * (float)width;
+        t.yw[k] = (cy[k] / cw[k] * 0.5f + 0.5f) * (float)height;
+        t.zw[k] = cz[k] / cw[k] * 0.5f + 0.5f;
+        t.iw[k] = 1.0f / cw[k];
+    }
+    const float area = (t.xw[1] - t.xw[0]) * (t.yw[2] - t.yw[0]) - (t.xw[2] - t.xw[0]) * (t.yw[1] - t.yw[0]);
+    if (!(area > 0.0f)) return false;  // back face (or degenerate): GL_CULL_FACE, front = counter-clockwise
+    const float minx = fminf(t.xw[0], fminf(t.xw[1], t.xw[2])), maxx = fmaxf(t.xw[0], fmaxf(t.xw[1], t.xw[2]));
+    const float miny = fminf(t.yw[0], fminf(t.yw[1], t.yw[2])), maxy = fmaxf(t.yw[0], fmaxf(t.yw[1], t.yw[2]));
+    t.x_lo = max(0, (int)ceilf(minx - 0.5f)), t.x_hi = min(width - 1, (int)floorf(maxx - 0.5f));
+    t.y_lo = max(0, (int)ceilf(miny - 0.5f)), t.y_hi = min(height - 1, (int)floorf(maxy - 0.5f));
+    if (t.x_lo > t.x_hi || t.y_lo > t.y_hi) return false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int a = (k + 1) % 3, b = (k + 2) % 3;
+        t.ex[k] = t.xw[b] - t.xw[a];
+        t.ey[k] = t.yw[b] - t.yw[a];
+        t.own[k] = edge_owner(t.ex[k], t.ey[k]);
+    }
+    t.inv_area = 1.0f / area;
+    return true;
+}
+
+__device__ __forceinline__ void tri_attributes(const TriView &t, const float (&tu)[3], const float (&tv)[3], float fxp, float fyp, float &u,
+                                               float &v, float &z, float (&bary)[3])
+{
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int a = (k + 1) % 3;
+        bary[k] = (t.ex[k] * (fyp - t.yw[a]) - t.ey[k] * (fxp - t.xw[a])) * t.inv_area;
+    }
+    z = bary[0] * t.zw[0] + bary[1] * t.zw[1] + bary[2] * t.zw[2];
+    const float q = bary[0] * t.iw[0] + bary[1] * t.iw[1] + bary[2] * t.iw[2];
+    u = (bary[0] * tu[0] * t.iw[0] + bary[1] * tu[1] * t.iw[1] + bary[2] * tu[2] * t.iw[2]) / q;
+    v = (bary[0] * tv[0] * t.iw[0] + bary[1] * tv[1] * t.iw[1] + bary[2] * tv[2] * t.iw[2]) / q;
+}
+
+// Coverage test + depth + texture + depth-tested write of pixel (xx, yy).
+__device__ __forceinline__ void tri_shade(const TriView &t, const float (&tu)[3], const float (&tv)[3], const MeshTexture &tex, int xx, int yy,
+                                          uint32_t *__restrict__ img, int width)
+{
+    const float fxp = (float)xx + 0.5f, fyp = (float)yy + 0.5f;
+    float bary[3], u, v, z;
+    tri_attributes(t, tu, tv, fxp, fyp, u, v, z, bary);
+    bool inside = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) inside = inside && (bary[k] > 0.0f || (bary[k] == 0.0f && t.own[k]));
+    if (!inside) return;
+    if (!(z >= 0.0f && z <= 1.0f)) return;  // depth clipping
+    float b2[3], ux, vx, uy, vy, zz;
+    tri_attributes(t, tu, tv, fxp + 1.0f, fyp, ux, vx, zz, b2);
+    tri_attributes(t, tu, tv, fxp, fyp + 1.0f, uy, vy, zz, b2);
     const float tw = (float)tex.w[0], th = (float)tex.h[0];
+    const float dudx = (ux - u) * tw, dvdx = (vx - v) * th, dudy = (uy - u) * tw, dvdy = (vy - v) * th;
+    const float rho = fmaxf(sqrtf(dudx * dudx + dvdx * dvdx), sqrtf(dudy * dudy + dvdy * dvdy));
+    float luma;
+    const float lambda = log2f(rho);
+    if (!(lambda > 0.0f)) {
+        luma = tex_bilinear(tex, 0, u, v);  // magnification: GL_LINEAR on the base level
+    } else {
+        const float lc = fminf(lambda, (float)(tex.levels - 1));
+        const int l0 = (int)floorf(lc), l1 = min(l0 + 1, tex.levels - 1);
+        const float f = lc - (float)l0;
+        const float s0 = tex_bilinear(tex, l0, u, v), s1 = tex_bilinear(tex, l1, u, v);
+        luma = s0 + (s1 - s0) * f;   // GL_LINEAR_MIPMAP_LINEAR
+    }
+    const uint32_t colour = (uint32_t)(fminf(fmaxf(luma, 0.0f), 1.0f) * 255.0f + 0.5f);
+    const uint32_t depth = (uint32_t)(z * 16777215.0f + 0.5f);
+    atomicMin(&img[(size_t)yy * width + xx], (depth << 8) | colour);
+}
+
+// Rasterisation in two kernels.
+//  nmi_mesh_kernel       one lane per triangle, looping over the views (the mesh is read once).  A triangle whose pixel
+//                        bounding box in a view is at most kSmallBox pixels is shaded right there by its lane; a larger one
+//                        is cut into 64 x 64 pixel screen tiles and each (triangle, view, tile) goes into a work queue.
+//  nmi_mesh_tile_kernel  one wavefront per queue entry: it rebuilds the TriView (the same arithmetic) and sweeps the
+//                        tile's part of the bounding box, 64 pixels of a row at a time.
+// A lane walking a 2,000-pixel triangle alone (facades, floors: the meshes this renderer is for) kept its wavefront busy
+// 30 times longer than the other 63 lanes needed: 38 ms for 27 views of a 4,800-triangle plane, against 0.5 ms for the
+// same plane in 1.9 M triangles.  If the queue is full the lane shades the triangle itself (slow, still exact).
+constexpr int kSmallBox = 16;
+constexpr int kTile = 64;
+
+struct TileItem {
+    uint32_t tri;
+    uint32_t where;  // view | tile x << 8 | tile y << 20
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void nmi_mesh_kernel(const float *__restrict__ xyz, const float *__restrict__ uv, long long ntri,
+                                                       const float *__restrict__ mvps, int views, uint32_t *__restrict__ zbuf,
+                                                       int width, int height, MeshTexture tex, TileItem *__restrict__ queue,
+                                                       unsigned long long *__restrict__ queue_state, unsigned long long queue_cap)
+{
+    // queue_state[0]: entries claimed so far.  Claims are contiguous, so at most one claim straddles the capacity and
+    // every later one lies beyond it: the entries actually written are [0, start of the first claim that did not fit),
+    // and queue_state[1] holds the bitwise NOT of that start (atomicMax from 0, so one memset resets both words).
+    __shared__ float m_all[kMaxViewsPerLaunch * 16];
+    __shared__ float wave_box[4][6];
+    __shared__ uint32_t beyond[kMaxViewsPerLaunch];
+    for (int t = threadIdx.x; t < views * 16; t += blockDim.x) m_all[t] = mvps[t];
+    for (int t = threadIdx.x; t < views; t += blockDim.x) beyond[t] = 0x3Fu;
+    const long long tri = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const bool valid = tri < ntri;
+    float px[3] = {0, 0, 0}, py[3] = {0, 0, 0}, pz[3] = {0, 0, 0}, tu[3] = {0, 0, 0}, tv[3] = {0, 0, 0};
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            px[k] = xyz[(tri * 3 + k) * 3], py[k] = xyz[(tri * 3 + k) * 3 + 1], pz[k] = xyz[(tri * 3 + k) * 3 + 2];
+            tu[k] = uv[(tri * 3 + k) * 2], tv[k] = uv[(tri * 3 + k) * 2 + 1];
+        }
+    }
+    {
+        // a triangle all of whose corners are beyond one clip plane is rejected by tri_setup; the block's box decides
+        // that for its 256 triangles at once (block_frustum_cull)
+        const float inf = __builtin_huge_valf();
+        const float lo[3] = {valid ? fminf(px[0], fminf(px[1], px[2])) : inf, valid ? fminf(py[0], fminf(py[1], py[2])) : inf,
+                             valid ? fminf(pz[0], fminf(pz[1], pz[2])) : inf};
+        const float hi[3] = {valid ? fmaxf(px[0], fmaxf(px[1], px[2])) : -inf, valid ? fmaxf(py[0], fmaxf(py[1], py[2])) : -inf,
+                             valid ? fmaxf(pz[0], fmaxf(pz[1], pz[2])) : -inf};
+        block_frustum_cull(m_all, views, lo, hi, wave_box, beyond);
+    }
+    if (!valid) return;
     for (int s = 0; s < views; ++s) {
-        const float *m = m_all + s * 16;
-        float cx[3], cy[3], cz[3], cw[3];
-        bool behind = false;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            cx[k] = (m[0] * px[k] + m[4] * py[k]) + (m[8] * pz[k] + m[12]);
-            cy[k] = (m[1] * px[k] + m[5] * py[k]) + (m[9] * pz[k] + m[13]);
-            cz[k] = (m[2] * px[k] + m[6] * py[k]) + (m[10] * pz[k] + m[14]);
-            cw[k] = (m[3] * px[k] + m[7] * py[k]) + (m[11] * pz[k] + m[15]);
-            behind = behind || !(cw[k] > 0.0f);
+        if (beyond[s]) continue;  // block-uniform
+        TriView t;
+        if (!tri_setup(m_all + s * 16, px, py, pz, width, height, t)) continue;
+        const int bw = t.x_hi - t.x_lo + 1, bh = t.y_hi - t.y_lo + 1;
+        if (bw * bh > kSmallBox && queue != nullptr && tri <= 0xFFFFFFFFll) {
+            const int tx0 = t.x_lo / kTile, tx1 = t.x_hi / kTile, ty0 = t.y_lo / kTile, ty1 = t.y_hi / kTile;
+            const unsigned long long n = (unsigned long long)((tx1 - tx0 + 1) * (ty1 - ty0 + 1));
+            const unsigned long long at = atomicAdd(&queue_state[0], n);
+            if (at + n <= queue_cap) {
+                unsigned long long k = at;
+                for (int ty = ty0; ty <= ty1; ++ty)
+                    for (int tx = tx0; tx <= tx1; ++tx) queue[k++] = TileItem{(uint32_t)tri, (uint32_t)s | ((uint32_t)tx << 8) | ((uint32_t)ty << 20)};
+                continue;
+            }
+            atomicMax(&queue_state[1], ~at);  // queue full: this lane does the work itself (below)
         }
-        if (behind) continue;
-        if ((cx[0] < -cw[0] && cx[1] < -cw[1] && cx[2] < -cw[2]) || (cx[0] > cw[0] && cx[1] > cw[1] && cx[2] > cw[2]) ||
-            (cy[0] < -cw[0] && cy[1] < -cw[1] && cy[2] < -cw[2]) || (cy[0] > cw[0] && cy[1] > cw[1] && cy[2] > cw[2]) ||
-            (cz[0] < -cw[0] && cz[1] < -cw[1] && cz[2] < -cw[2]) || (cz[0] > cw[0] && cz[1] > cw[1] && cz[2] > cw[2]))
-            continue;
-        float xw[3], yw[3], zw[3], iw[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            xw[k] = (cx[k] / cw[k] * 0.5f + 0.5f) * (float)width;
-            yw[k] = (cy[k] / cw[k] * 0.5f + 0.5f) * (float)height;
-            zw[k] = cz[k] / cw[k] * 0.5f + 0.5f;
-            iw[k] = 1.0f / cw[k];
-        }
-        const float area = (xw[1] - xw[0]) * (yw[2] - yw[0]) - (xw[2] - xw[0]) * (yw[1] - yw[0]);
-        if (!(area > 0.0f)) continue;  // back face (or degenerate): GL_CULL_FACE, front = counter-clockwise
-        const float minx = fminf(xw[0], fminf(xw[1], xw[2])), maxx = fmaxf(xw[0], fmaxf(xw[1], xw[2]));
-        const float miny = fminf(yw[0], fminf(yw[1], yw[2])), maxy = fmaxf(yw[0], fmaxf(yw[1], yw[2]));
-        const int x_lo = max(0, (int)ceilf(minx - 0.5f)), x_hi = min(width - 1, (int)floorf(maxx - 0.5f));
-        const int y_lo = max(0, (int)ceilf(miny - 0.5f)), y_hi = min(height - 1, (int)floorf(maxy - 0.5f));
-        if (x_lo > x_hi || y_lo > y_hi) continue;
-        // edge k is opposite vertex k: from vertex (k+1)%3 to vertex (k+2)%3
-        float ex[3], ey[3];
-        bool own[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int a = (k + 1) % 3, b = (k + 2) % 3;
-            ex[k] = xw[b] - xw[a];
-            ey[k] = yw[b] - yw[a];
-            own[k] = edge_owner(ex[k], ey[k]);
-        }
-        const float inv_area = 1.0f / area;
         uint32_t *img = zbuf + (size_t)s * width * height;
-        auto attributes = [&](float fxp, float fyp, float &u, float &v, float &z, float (&bary)[3]) {
+        for (int yy = t.y_lo; yy <= t.y_hi; ++yy)
+            for (int xx = t.x_lo; xx <= t.x_hi; ++xx) tri_shade(t, tu, tv, tex, xx, yy, img, width);
+    }
+}
+
+__global__ __launch_bounds__(64) void nmi_mesh_tile_kernel(const float *__restrict__ xyz, const float *__restrict__ uv,
+                                                           const float *__restrict__ mvps, uint32_t *__restrict__ zbuf, int width, int height,
+                                                           MeshTexture tex, const TileItem *__restrict__ queue,
+                                                           const unsigned long long *__restrict__ queue_state)
+{
+    const unsigned long long claimed = queue_state[0], first_unfit = ~queue_state[1];
+    const unsigned long long count = claimed < first_unfit ? claimed : first_unfit;  // the written prefix (see nmi_mesh_kernel)
+    const int lane = threadIdx.x;
+    for (unsigned long long i = blockIdx.x; i < count; i += gridDim.x) {
+        const TileItem it = queue[i];
+        const long long tri = it.tri;
+        const int s = (int)(it.where & 0xFFu), tx = (int)((it.where >> 8) & 0xFFFu), ty = (int)(it.where >> 20);
+        float px[3], py[3], pz[3], tu[3], tv[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int a = (k + 1) % 3;
-                bary[k] = (ex[k] * (fyp - yw[a]) - ey[k] * (fxp - xw[a])) * inv_area;
-            }
-            z = bary[0] * zw[0] + bary[1] * zw[1] + bary[2] * zw[2];
-            const float q = bary[0] * iw[0] + bary[1] * iw[1] + bary[2] * iw[2];
-            u = (bary[0] * tu[0] * iw[0] + bary[1] * tu[1] * iw[1] + bary[2] * tu[2] * iw[2]) / q;
-            v = (bary[0] * tv[0] * iw[0] + bary[1] * tv[1] * iw[1] + bary[2] * tv[2] * iw[2]) / q;
-        };
-        for (int yy = y_lo; yy <= y_hi; ++yy) {
-            for (int xx = x_lo; xx <= x_hi; ++xx) {
-                const float fxp = (float)xx + 0.5f, fyp = (float)yy + 0.5f;
-                float bary[3], u, v, z;
-                attributes(fxp, fyp, u, v, z, bary);
-                bool inside = true;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) inside = inside && (bary[k] > 0.0f || (bary[k] == 0.0f && own[k]));
-                if (!inside) continue;
-                if (!(z >= 0.0f && z <= 1.0f)) continue;  // depth clipping
-                float b2[3], ux, vx, uy, vy, zz;
-                attributes(fxp + 1.0f, fyp, ux, vx, zz, b2);
-                attributes(fxp, fyp + 1.0f, uy, vy, zz, b2);
-                const float dudx = (ux - u) * tw, dvdx = (vx - v) * th, dudy = (uy - u) * tw, dvdy = (vy - v) * th;
-                const float rho = fmaxf(sqrtf(dudx * dudx + dvdx * dvdx), sqrtf(dudy * dudy + dvdy * dvdy));
-                float luma;
-                const float lambda = log2f(rho);
-                if (!(lambda > 0.0f)) {
-                    luma = tex_bilinear(tex, 0, u, v);  // magnification: GL_LINEAR on the base level
-                } else {
-                    const float lc = fminf(lambda, (float)(tex.levels - 1));
-                    const int l0 = (int)floorf(lc), l1 = min(l0 + 1, tex.levels - 1);
-                    const float f = lc - (float)l0;
-                    const float s0 = tex_bilinear(tex, l0, u, v), s1 = tex_bilinear(tex, l1, u, v);
-                    luma = s0 + (s1 - s0) * f;   // GL_LINEAR_MIPMAP_LINEAR
-                }
-                const uint32_t colour = (uint32_t)(fminf(fmaxf(luma, 0.0f), 1.0f) * 255.0f + 0.5f);
-                const uint32_t depth = (uint32_t)(z * 16777215.0f + 0.5f);
-                atomicMin(&img[(size_t)yy * width + xx], (depth << 8) | colour);
-            }
+        for (int k = 0; k < 3; ++k) {
+            px[k] = xyz[(tri * 3 + k) * 3], py[k] = xyz[(tri * 3 + k) * 3 + 1], pz[k] = xyz[(tri * 3 + k) * 3 + 2];
+            tu[k] = uv[(tri * 3 + k) * 2], tv[k] = uv[(tri * 3 + k) * 2 + 1];
         }
+        TriView t;
+        if (!tri_setup(mvps + s * 16, px, py, pz, width, height, t)) continue;  // cannot happen: the same test passed before
+        const int x0 = max(t.x_lo, tx * kTile), x1 = min(t.x_hi, tx * kTile + kTile - 1);
+        const int y0 = max(t.y_lo, ty * kTile), y1 = min(t.y_hi, ty * kTile + kTile - 1);
+        uint32_t *img = zbuf + (size_t)s * width * height;
+        // the wavefront is an 8 x 8 pixel stamp (a 9 x 8 box is two steps, not eight rows of nine lanes)
+        const int lx = lane & 7, ly = lane >> 3;
+        for (int by = y0; by <= y1; by += 8)
+            for (int bx = x0; bx <= x1; bx += 8) {
+                const int xx = bx + lx, yy = by + ly;
+                if (xx <= x1 && yy <= y1) tri_shade(t, tu, tv, tex, xx, yy, img, width);
+            }
     }
 }
 
 hipError_t launch_render_mesh(const float *xyz, const float *uv, long long ntri, const float *luma, int levels, const int *lw,
                               const int *lh, const long long *loff, const float *mvps, int S, uint32_t *zbuf, uint8_t *out,
-                              int width, int height, hipStream_t stream)
+                              int width, int height, void *tile_queue, unsigned long long tile_queue_cap, unsigned long long *queue_state,
+                              hipStream_t stream, bool clear_first)
 {
     MeshTexture tex{};
     tex.luma = luma;
     tex.levels = levels;
     for (int l = 0; l < levels && l < 16; ++l) tex.w[l] = lw[l], tex.h[l] = lh[l], tex.off[l] = loff[l];
     const size_t nz = (size_t)S * width * height;
-    hipLaunchKernelGGL(nmi_zbuf_clear_kernel, dim3((unsigned)((nz + 255) / 256 < 4096 ? (nz + 255) / 256 : 4096)), dim3(256), 0, stream, zbuf, nz);
+    if (clear_first)
+        hipLaunchKernelGGL(nmi_zbuf_clear_kernel, dim3((unsigned)((nz + 255) / 256 < 4096 ? (nz + 255) / 256 : 4096)), dim3(256), 0, stream, zbuf, nz);
     if (ntri > 0) {
+        TileItem *queue = tile_queue_cap > 0 && queue_state ? static_cast<TileItem *>(tile_queue) : nullptr;
         for (int s0 = 0; s0 < S; s0 += kMaxViewsPerLaunch) {
             const int views = S - s0 < kMaxViewsPerLaunch ? S - s0 : kMaxViewsPerLaunch;
+            if (queue) {
+                const hipError_t e = hipMemsetAsync(queue_state, 0, 2 * sizeof(unsigned long long), stream);
+                if (e != hipSuccess) return e;
+            }
             hipLaunchKernelGGL(nmi_mesh_kernel, dim3((unsigned)((ntri + 255) / 256)), dim3(256), 0, stream, xyz, uv, ntri,
-                               mvps + (size_t)s0 * 16, views, zbuf + (size_t)s0 * width * height, width, height, tex);
+                               mvps + (size_t)s0 * 16, views, zbuf + (size_t)s0 * width * height, width, height, tex, queue, queue_state,
+                               tile_queue_cap);
+            if (queue)
+                hipLaunchKernelGGL(nmi_mesh_tile_kernel, dim3(16384), dim3(64), 0, stream, xyz, uv, mvps + (size_t)s0 * 16,
+                                   zbuf + (size_t)s0 * width * height, width, height, tex, queue, queue_state);
         }
     }
     launch_resolve(zbuf, out, S, width, height, 1, stream);
     return hipGetLastError();
 }
+
+size_t mesh_tile_item_bytes() { return sizeof(TileItem); }
 
 hipError_t launch_render_points(const float *xyz, const float *red, long long npoints, const float *mvps, int S, uint32_t *zbuf,
                                 uint8_t *out, int width, int height, int size, hipStream_t stream, bool clear_first)

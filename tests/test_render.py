@@ -258,6 +258,30 @@ def test_gpu_mesh_vs_twin():
 
 
 @pytest.mark.gpu
+def test_gpu_mesh_large_triangles_and_queue_overflow():
+    """Large triangles go through the (triangle, view, tile) queue and the tile kernel; with the queue shortened so that it
+    overflows, or switched off, the lanes of the first pass shade the excess themselves.  All three give the same images,
+    equal to the twin's: a plane of 6 x 4 quads (triangles of ~1,000 pixels spanning several 64 x 64 tiles), seen from 5 poses."""
+    torch = pytest.importorskip("torch")
+    import orbslam2_nmi_amd as nmi
+    w, h = 320, 200
+    xyz, uv, rgb, rp = plane_mesh(w, h, nx=6, ny=4)
+    mvps = np.stack([capi.render_mvp(rp, (0, 0, 0), (0, 0, 1), (0, -1, 0), t)
+                     for t in ((0, 0, 0), (0.4, -0.3, 1.0), (-0.8, 0.2, -3.0), (2.5, 0, 0), (0, 1.5, 2.0))])
+    exp = mo.render_stack(xyz, uv, mo.mip_luma(rgb), mvps, w, h)
+    outs = []
+    with nmi.NmiContext(w, h) as ctx, nmi.NmiTexture(ctx, rgb) as tex:
+        dx, du = torch.from_numpy(xyz).cuda(), torch.from_numpy(uv).cuda()
+        for cap in (4 << 20, 37, 0):
+            ctx.set_option(ctx.OPT_TILE_QUEUE, cap)
+            outs.append(ctx.render_mesh(dx, du, tex, mvps).cpu().numpy())
+    assert (outs[0] == outs[1]).all() and (outs[0] == outs[2]).all()
+    diff = np.abs(outs[0].astype(int) - exp.astype(int))
+    assert ((outs[0] == 255) == (exp == 255)).all()
+    assert diff.max() <= 1 and (diff != 0).mean() < 2e-3, (diff.max(), (diff != 0).mean())
+
+
+@pytest.mark.gpu
 def test_gpu_mesh_to_winner_end_to_end():
     """mesh + texture + pose -> device render stack for a 3x3x1 translation grid; the frame is the mesh seen from a
     displaced pose (other gamma + noise); the search picks the nearest cell."""
