@@ -194,6 +194,9 @@ int nmi_render_mesh(nmi_ctx *ctx, const float *d_xyz, const float *d_uv, int64_t
 typedef struct nmi_level nmi_level;
 int nmi_level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int64_t n_points, const uint8_t *d_frame, int32_t S,
                      int32_t Wn, float point_size, nmi_level **out);
+/* The same with the textured mesh as the map (nmi_prop_RENDER 1): d_xyz / d_uv / tex as for nmi_render_mesh. */
+int nmi_level_create_mesh(nmi_ctx *ctx, const float *d_xyz, const float *d_uv, int64_t n_triangles, const nmi_texture *tex,
+                          const uint8_t *d_frame, int32_t S, int32_t Wn, nmi_level **out);
 int nmi_level_run(nmi_level *lv, const float *h_mvps, const double *h_forward, int64_t *h_best_index, float *h_best_score);
 int nmi_level_destroy(nmi_level *lv);
 

@@ -23,7 +23,7 @@ ERR_NOT_READY = -4
 # Every symbol include/nmi_hip.h declares; tests check that the library exports all of them.
 EXPORTED_SYMBOLS = (
     "nmi_params_default", "nmi_create", "nmi_destroy", "nmi_set_stream", "nmi_synchronize", "nmi_eval_pair", "nmi_eval_pair_debug",
-    "nmi_search_grid", "nmi_search_grid_shard", "nmi_warp_homographies", "nmi_warp_stack", "nmi_render_mvp", "nmi_render_points", "nmi_level_create", "nmi_level_run", "nmi_level_destroy", "nmi_texture_create",
+    "nmi_search_grid", "nmi_search_grid_shard", "nmi_warp_homographies", "nmi_warp_stack", "nmi_render_mvp", "nmi_render_points", "nmi_level_create", "nmi_level_create_mesh", "nmi_level_run", "nmi_level_destroy", "nmi_texture_create",
     "nmi_texture_destroy", "nmi_render_mesh", "nmi_stream_create", "nmi_stream_destroy",
     "nmi_stream_submit", "nmi_stream_wait", "nmi_key_pack", "nmi_key_unpack", "nmi_search_grid_rccl",
     "nmi_rccl_unique_id", "nmi_rccl_comm_init", "nmi_rccl_comm_destroy", "nmi_set_profiling", "nmi_last_kernel_ms",
@@ -87,6 +87,7 @@ def load_library(build_if_missing=False):
     lib.nmi_texture_destroy.argtypes = [vp]
     lib.nmi_render_mesh.argtypes = [vp, vp, vp, C.c_int64, vp, f32p, i32, vp]
     lib.nmi_level_create.argtypes = [vp, vp, vp, C.c_int64, vp, i32, i32, C.c_float, C.POINTER(vp)]
+    lib.nmi_level_create_mesh.argtypes = [vp, vp, vp, C.c_int64, vp, vp, i32, i32, C.POINTER(vp)]
     lib.nmi_level_run.argtypes = [vp, f32p, C.POINTER(C.c_double), i64p, f32p]
     lib.nmi_level_destroy.argtypes = [vp]
     lib.nmi_stream_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
@@ -425,14 +426,20 @@ class NmiTexture:
 class NmiLevel:
     """nmi_level wrapper: cloud + frame -> renders, warps, search, winner as one captured HIP graph."""
 
-    def __init__(self, ctx, xyz, red, frame, S, Wn, point_size):
+    def __init__(self, ctx, xyz, red, frame, S, Wn, point_size, texture=None):
+        """Point cloud: xyz [N,3], red [N], point_size.  Textured mesh: pass texture=NmiTexture, xyz [3T,3] corner
+        positions and `red` = uv [3T,2] (point_size is ignored)."""
         self.ctx, self._lib = ctx, ctx._lib
-        self._keep = (xyz, red, frame)  # the graph holds their device addresses
+        self._keep = (xyz, red, frame, texture)  # the graph holds their device addresses
         self.S, self.Wn = int(S), int(Wn)
         self._h = C.c_void_p()
         ctx._order_after_torch()
-        ctx._check(self._lib.nmi_level_create(ctx._h, xyz.data_ptr(), red.data_ptr(), xyz.shape[0], frame.data_ptr(), self.S,
-                                              self.Wn, float(point_size), C.byref(self._h)), "nmi_level_create")
+        if texture is None:
+            ctx._check(self._lib.nmi_level_create(ctx._h, xyz.data_ptr(), red.data_ptr(), xyz.shape[0], frame.data_ptr(), self.S,
+                                                  self.Wn, float(point_size), C.byref(self._h)), "nmi_level_create")
+        else:
+            ctx._check(self._lib.nmi_level_create_mesh(ctx._h, xyz.data_ptr(), red.data_ptr(), xyz.shape[0] // 3, texture._h,
+                                                       frame.data_ptr(), self.S, self.Wn, C.byref(self._h)), "nmi_level_create_mesh")
 
     def run(self, mvps, homographies):
         m = np.ascontiguousarray(mvps, np.float32).reshape(-1)

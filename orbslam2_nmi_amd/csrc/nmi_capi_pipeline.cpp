@@ -54,15 +54,25 @@ int nmi_level_destroy(nmi_level *lv)
     return NMI_OK;
 }
 
-int nmi_level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int64_t n_points, const uint8_t *d_frame, int32_t S,
-                     int32_t Wn, float point_size, nmi_level **out)
+}  // extern "C"
+
+// Common part of nmi_level_create (tex == nullptr: coloured points, d_attr = red) and nmi_level_create_mesh (tex: textured
+// triangles, d_attr = uv, n = triangles).
+static int level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_attr, int64_t n_points, const nmi_texture *tex,
+                        const uint8_t *d_frame, int32_t S, int32_t Wn, float point_size, nmi_level **out)
 {
-    if (!ctx || !out || !d_frame || S <= 0 || Wn <= 0 || n_points < 0 || (n_points > 0 && (!d_xyz || !d_red)))
+    const float *d_red = d_attr;
+    if (!ctx || !out || !d_frame || S <= 0 || Wn <= 0 || n_points < 0 || (n_points > 0 && (!d_xyz || !d_attr)))
         return NMI_ERR_INVALID_ARGUMENT;
+    if (tex && tex->ctx != ctx) return NMI_ERR_INVALID_ARGUMENT;
     if (!ctx->params.use_bg) return NMI_ERR_UNSUPPORTED;
     *out = nullptr;
     ctx->detail.clear();
     DeviceGuard guard(ctx->device);
+    if (tex) {
+        const int rq = ensure_tile_queue(ctx);
+        if (rq != NMI_OK) return rq;
+    }
     nmi_level *lv = new (std::nothrow) nmi_level;
     if (!lv) return NMI_ERR_INVALID_ARGUMENT;
     lv->ctx = ctx;
@@ -143,8 +153,14 @@ int nmi_level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int64
         ok(hipStreamWaitEvent(lv->side, lv->ev_fork, 0));
         ok(nmi::launch_warp(d_frame, lv->d_coeffs, lv->d_warps, p.width, p.height, Wn, lv->side));
         ok(hipEventRecord(lv->ev_join, lv->side));
-        ok(nmi::launch_render_points(d_xyz, d_red, n_points, lv->d_mvps, S, lv->d_zbuf, lv->d_renders, p.width, p.height, lv->size, st,
-                                     /*clear_first=*/false));
+        if (tex)
+            ok(nmi::launch_render_mesh(d_xyz, d_attr, n_points, tex->d_luma, tex->levels, tex->w, tex->h, tex->off, lv->d_mvps, S, lv->d_zbuf,
+                                       lv->d_renders, p.width, p.height, ctx->d_tile_queue,
+                                       ctx->tile_queue_limit < ctx->tile_queue_cap ? ctx->tile_queue_limit : ctx->tile_queue_cap,
+                                       ctx->d_tile_state, st, /*clear_first=*/false));
+        else
+            ok(nmi::launch_render_points(d_xyz, d_red, n_points, lv->d_mvps, S, lv->d_zbuf, lv->d_renders, p.width, p.height, lv->size, st,
+                                         /*clear_first=*/false));
         ok(hipStreamWaitEvent(st, lv->ev_join, 0));
         ok(nmi::launch_grid(a, workgroups, true, st));
         hipError_t ec = hipStreamEndCapture(st, &lv->graph);
@@ -158,6 +174,21 @@ int nmi_level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int64
     }
     *out = lv;
     return NMI_OK;
+}
+
+extern "C" {
+
+int nmi_level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int64_t n_points, const uint8_t *d_frame, int32_t S,
+                     int32_t Wn, float point_size, nmi_level **out)
+{
+    return level_create(ctx, d_xyz, d_red, n_points, nullptr, d_frame, S, Wn, point_size, out);
+}
+
+int nmi_level_create_mesh(nmi_ctx *ctx, const float *d_xyz, const float *d_uv, int64_t n_triangles, const nmi_texture *tex,
+                          const uint8_t *d_frame, int32_t S, int32_t Wn, nmi_level **out)
+{
+    if (!tex) return NMI_ERR_INVALID_ARGUMENT;
+    return level_create(ctx, d_xyz, d_uv, n_triangles, tex, d_frame, S, Wn, 1.0f, out);
 }
 
 int nmi_level_run(nmi_level *lv, const float *h_mvps, const double *h_forward, int64_t *h_best_index, float *h_best_score)

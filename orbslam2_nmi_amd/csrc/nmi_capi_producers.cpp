@@ -4,6 +4,23 @@
 
 using namespace nmi_internal;
 
+namespace nmi_internal {
+
+// Work queue of the mesh renderer's large-triangle pass: 4 M (triangle, view, 64x64 tile) items = 32 MiB, allocated on
+// first use.  Meshes that need more (the lanes of the first pass then shade the excess themselves) are far beyond a map
+// of textured facades.
+int ensure_tile_queue(nmi_ctx *ctx)
+{
+    if (ctx->d_tile_queue) return NMI_OK;
+    constexpr unsigned long long kItems = 4ull << 20;
+    NMI_HIP_TRY(ctx, hipMalloc(&ctx->d_tile_queue, (size_t)kItems * nmi::mesh_tile_item_bytes()));
+    ctx->tile_queue_cap = kItems;
+    NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tile_state, 2 * sizeof(unsigned long long)));
+    return NMI_OK;
+}
+
+}  // namespace nmi_internal
+
 extern "C" {
 
 // Image::Image warp matrices, image.cpp:76-107: theta_a starts at -(n_a - 1)/2 * step_a with the integer division
@@ -151,14 +168,6 @@ int nmi_render_points(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int6
 // ---------------------------------------------------------------------------------------------------------
 }  // extern "C"
 
-struct nmi_texture {
-    nmi_ctx *ctx = nullptr;
-    float *d_luma = nullptr;
-    int levels = 0;
-    int w[16] = {}, h[16] = {};
-    long long off[16] = {};
-};
-
 extern "C" {
 
 int nmi_texture_destroy(nmi_texture *tex)
@@ -242,14 +251,8 @@ int nmi_render_mesh(nmi_ctx *ctx, const float *d_xyz, const float *d_uv, int64_t
         NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_zbuf, (size_t)need * sizeof(uint32_t)));
         ctx->zbuf_cap = need;
     }
-    if (!ctx->d_tile_queue) {
-        // Work queue of the large-triangle pass: 4 M (triangle, view, 64x64 tile) items = 32 MiB.  Meshes that need more
-        // (the lanes of the first pass then shade the excess themselves) are far beyond a map of textured facades.
-        constexpr unsigned long long kItems = 4ull << 20;
-        NMI_HIP_TRY(ctx, hipMalloc(&ctx->d_tile_queue, (size_t)kItems * nmi::mesh_tile_item_bytes()));
-        ctx->tile_queue_cap = kItems;
-        NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tile_state, 2 * sizeof(unsigned long long)));
-    }
+    int rq = ensure_tile_queue(ctx);
+    if (rq != NMI_OK) return rq;
     float *d_mvps = nullptr;
     int rc = stage_floats(ctx, ctx->mvp_ring, h_mvps, (size_t)S * 16, &d_mvps);
     if (rc != NMI_OK) return rc;

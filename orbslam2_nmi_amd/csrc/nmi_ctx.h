@@ -77,7 +77,18 @@ struct nmi_ctx {
     std::string detail;
 };
 
+// nmi_texture (nmi_texture_create): mip chain of a mesh texture as per-level fp32 luma on the device.
+struct nmi_texture {
+    nmi_ctx *ctx = nullptr;
+    float *d_luma = nullptr;
+    int levels = 0;
+    int w[16] = {}, h[16] = {};
+    long long off[16] = {};
+};
+
 namespace nmi_internal {
+
+int ensure_tile_queue(nmi_ctx *ctx);
 
 int hip_fail(nmi_ctx *ctx, hipError_t e, const char *what);
 int ensure_ratings(nmi_ctx *ctx, int64_t n);

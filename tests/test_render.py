@@ -307,3 +307,32 @@ def test_gpu_mesh_to_winner_end_to_end():
         t = torch.zeros(1, 9, device="cuda")
         idx, best = ctx.search_grid(rs, frame[None], t)
     assert cells[idx] == truth and best > 1.3 * np.sort(t.cpu().numpy().reshape(-1))[-2]
+
+
+@pytest.mark.gpu
+def test_gpu_mesh_level_graph_equals_separate_calls():
+    """nmi_level_create_mesh: mesh renders + warps + search + winner as one captured HIP graph give exactly what the three
+    calls give, replay after replay with changing matrices (triangles large enough to take the tile queue)."""
+    torch = pytest.importorskip("torch")
+    import orbslam2_nmi_amd as nmi
+    from orbslam2_nmi_amd import hostapi as H
+    w, h = 160, 120
+    xyz, uv, rgb, rp = plane_mesh(w, h, nx=12, ny=9)
+    Twc = np.eye(4, dtype=np.float32)
+    Twc[:3, 1] = [0, -1, 0]
+    pos, look, up = Twc[:3, 3], Twc[:3, 3] + Twc[:3, 2], Twc[:3, 1]
+    cells = [(sx, sy_, sz) for sz in range(2) for sy_ in range(2) for sx in range(2)]
+    K = sy.intrinsics(w, h)
+    with nmi.NmiContext(w, h) as ctx, nmi.NmiTexture(ctx, rgb) as tex:
+        dx, du = torch.from_numpy(xyz).cuda(), torch.from_numpy(uv).cuda()
+        fr = ctx.render_mesh(dx, du, tex, capi.render_mvp(rp, pos, look, up, (0.05, 0, 0))[None])[0]
+        frame = torch.flip(fr, dims=[0]).contiguous()
+        with nmi.NmiLevel(ctx, dx, du, frame, 8, 12, 1.0, texture=tex) as lv:
+            for lvl in range(4):
+                g = H.SearchKernel.make([2, 2, 2, 3, 2, 2], [s / 2 ** lvl for s in (0.2, 0.2, 0.5, 0.02, 0.02, 0.05)])
+                mvps = np.stack([capi.render_mvp(rp, pos, look, up, H.calculate_translation(Twc, g, *c)) for c in cells])
+                Ms = capi.warp_homographies(K, (3, 2, 2), tuple(g.step[3:6]))
+                got = lv.run(mvps, Ms)
+                rs = ctx.render_mesh(dx, du, tex, mvps)
+                ws = ctx.warp_stack(frame, Ms)
+                assert got == ctx.search_grid(rs, ws), lvl
