@@ -408,7 +408,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8 histogram counts (u32), f32 entropy",
+            "dtype": "u8", "dtype_detail": "u8 pixels -> u32 histogram counts (integer, exact); f32 entropy terms and score",
             "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: 640x480 frame, 729-pose grid (27 renders x 27 warps) per GPU, "
                                    "256-bin NMI (SUC), render axis sharded by rank",

@@ -24,10 +24,12 @@ __device__ __forceinline__ float warp_tap(const uint8_t *__restrict__ src, int w
 __global__ __launch_bounds__(256) void nmi_warp_kernel(const uint8_t *__restrict__ frame, const float *__restrict__ coeffs,
                                                        uint8_t *__restrict__ out, int width, int height, int quads_per_row)
 {
+    // a block is 32 quads x 8 rows = a 128 x 8 pixel patch of one warp: its taps fall into a compact patch of the frame
+    // (a whole row per block spread them over up to 50 frame rows at the largest rotation of the grid)
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
     const int wi = blockIdx.z;
-    if (q >= quads_per_row) return;
+    if (q >= quads_per_row || y >= height) return;
     const float *c = coeffs + wi * 9;
     uint32_t packed = 0;
     uint8_t px[4];
@@ -77,7 +79,7 @@ hipError_t launch_warp(const uint8_t *frame, const float *coeffs, uint8_t *out, 
                        hipStream_t stream)
 {
     const int quads = (width + 3) / 4;
-    dim3 block(256), grid((quads + 255) / 256, height, Wn);
+    dim3 block(32, 8), grid((quads + 31) / 32, (height + 7) / 8, Wn);
     hipLaunchKernelGGL(nmi_warp_kernel, grid, block, 0, stream, frame, coeffs, out, width, height, quads);
     return hipGetLastError();
 }
