@@ -195,8 +195,9 @@ def run_e2e_config(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", default="c2", choices=["c2", "stream", "e2e"],
-                    help="c2 = BASELINE.json configs[1] (the headline line); stream = configs[4] shape on the local GPU")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "stream", "e2e"],
+                    help="c2 = BASELINE.json configs[1] (the headline line); c3 = configs[2] (960x540, 4096 candidates); c4 = the "
+                         "per-rank share of configs[3] (848x480, 64 renders x 64 warps); stream = configs[4] shape on the local GPU")
     ap.add_argument("--keyframes", type=int, default=100)
     ap.add_argument("--no-graph", action="store_true", help="e2e config: enqueue the level's operations one by one instead of a HIP graph")
     ap.add_argument("--gpus", type=int, default=1)
@@ -221,6 +222,14 @@ def main():
         return run_stream_config(args)
     if args.config == "e2e":
         return run_e2e_config(args)
+    global WIDTH, HEIGHT, S_PER_RANK, WN
+    workload_name = "BASELINE.json configs[1]: 640x480 frame, 729-pose grid (27 renders x 27 warps) per GPU"
+    if args.config == "c3":
+        WIDTH, HEIGHT, S_PER_RANK, WN = 960, 540, 64, 64
+        workload_name = "BASELINE.json configs[2]: 960x540 frame, 4096-pose grid (64 renders x 64 warps) per GPU"
+    elif args.config == "c4":
+        WIDTH, HEIGHT, S_PER_RANK, WN = 848, 480, 64, 64
+        workload_name = "BASELINE.json configs[3], one rank's share: 848x480 frames, 64 renders x 64 warps per GPU (x8 ranks = 32768)"
 
     import torch
 
@@ -394,7 +403,7 @@ def main():
         per_launch_evals = S_PER_RANK * WN
         achieved = per_launch_evals * algorithmic_bytes_per_eval(WIDTH, HEIGHT) / (kernel_ms * 1e-3) / 1e9
         out = {
-            "metric": "pose-candidate NMI evals/sec (640x480, 256 bins)",
+            "metric": f"pose-candidate NMI evals/sec ({WIDTH}x{HEIGHT}, 256 bins)",
             "value": evals_per_step * args.steps / elapsed,
             "unit": "evals/s",
             "n_gpus": world,
@@ -410,15 +419,14 @@ def main():
             "vs_baseline": None,
             "dtype": "u8", "dtype_detail": "u8 pixels -> u32 histogram counts (integer, exact); f32 entropy terms and score",
             "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: 640x480 frame, 729-pose grid (27 renders x 27 warps) per GPU, "
-                                   "256-bin NMI (SUC), render axis sharded by rank",
+            "config": {"workload": workload_name + ", 256-bin NMI (SUC), render axis sharded by rank",
                        "width": WIDTH, "height": HEIGHT, "renders_per_gpu": S_PER_RANK, "warps": WN,
                        "candidates_total": evals_per_step, "bins": BINS,
                        "collective": "none" if dist is None else
                        ("8-byte MAX all-reduce (RCCL) per step" if args.blocking or bucket == 1 else
                         f"MAX all-reduce (RCCL) of the 8-byte winners, {bucket} steps per message")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_pmc_traffic(),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_pmc_traffic() if args.config == "c2" else None,
                          "kernel": "nmi_grid_kernel", "kernel_ms": kernel_ms, "kernel_ms_exclusive": kernel_ms_exclusive,
                          "algorithmic_bytes_per_launch": per_launch_evals * algorithmic_bytes_per_eval(WIDTH, HEIGHT)},
         }
