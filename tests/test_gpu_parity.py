@@ -525,3 +525,38 @@ def test_fuzz_campaign_against_the_oracle(nmi):
     noise, posterised, flat bands / blocks, constant) -- whole rating tables and winners against the C oracle."""
     import fuzz_parity
     assert fuzz_parity.run(250, seed=11, verbose=False) <= SCORE_TOL
+
+
+def test_two_contexts_from_two_threads(nmi):
+    """One context per host thread (the library keeps no global mutable state besides the lazily resolved RCCL entry
+    points): two threads search different grids at the same time, each on its own context and stream, and every result is
+    the one the context gives alone."""
+    import threading
+    from orbslam2_nmi_amd import synthetic as sy
+    jobs = []
+    for seed, (w, h, S, Wn) in ((21, (320, 240, 9, 8)), (22, (160, 120, 12, 27))):
+        wl = sy.workload(w, h, S, Wn, seed=seed)
+        rs, ws = dev(wl["render_stack"]), dev(wl["warp_stack"])
+        with nmi.NmiContext(w, h) as ctx:
+            expect = ctx.search_grid(rs, ws)
+        jobs.append((w, h, rs, ws, expect))
+    errors = []
+
+    def worker(job):
+        w, h, rs, ws, expect = job
+        try:
+            with nmi.NmiContext(w, h) as ctx:
+                for _ in range(150):
+                    got = ctx.search_grid(rs, ws)
+                    if got != expect:
+                        errors.append((got, expect))
+                        return
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
