@@ -50,8 +50,14 @@ __global__ __launch_bounds__(256) void nmi_warp_kernel(const uint8_t *__restrict
                 const int x2 = x1 + 1, y2 = y1 + 1;
                 float t11, t21, t12, t22;
                 if (x1 >= 0 && x2 < width && y1 >= 0 && y2 < height) {  // all four taps inside: no per-tap border test
+                    // two (possibly odd-addressed) 16-bit loads instead of four byte loads: the kernel is bound by the
+                    // number of scattered load instructions, not by bytes (-12 %; fetching the sixteen taps of a lane's
+                    // four pixels as two 8-byte loads when they share a frame row was slower again: more tests than loads)
                     const uint8_t *p = frame + y1 * width + x1;
-                    t11 = (float)p[0], t21 = (float)p[1], t12 = (float)p[width], t22 = (float)p[width + 1];
+                    unsigned short top, bot;
+                    __builtin_memcpy(&top, p, 2);
+                    __builtin_memcpy(&bot, p + width, 2);
+                    t11 = (float)(top & 0xFFu), t21 = (float)(top >> 8), t12 = (float)(bot & 0xFFu), t22 = (float)(bot >> 8);
                 } else {
                     t11 = warp_tap(frame, width, height, x1, y1), t21 = warp_tap(frame, width, height, x2, y1);
                     t12 = warp_tap(frame, width, height, x1, y2), t22 = warp_tap(frame, width, height, x2, y2);
