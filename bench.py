@@ -49,9 +49,18 @@ def cpu_baseline(wl, budget_s=12.0, max_threads=16):
         if time.perf_counter() - t0 >= budget_s:
             break
     dt = time.perf_counter() - t0
+    # SURVEY.md 8(d) also asks for the single-thread figure: one pair at a time, 256 bins and 64 bins (BASELINE configs[0])
+    single = {}
+    for bins, shift in ((256, 0), (64, 2)):
+        n, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < 0.7:
+            oc.eval_pair(rs[n % rs.shape[0]], ws[n % ws.shape[0]], shift=shift, render_bottom_up=wl["bottom_up"])
+            n += 1
+        single[f"evals_per_s_{bins}_bins"] = n / (time.perf_counter() - t1)
     return {"value": evals / dt, "unit": "evals/s", "cores": threads, "kind": "port",
             "sample": f"{reps} x the same {rs.shape[0]}x{ws.shape[0]} grid at {WIDTH}x{HEIGHT}, {BINS} bins, "
-                      f"OpenMP over candidates, {dt:.1f} s"}
+                      f"OpenMP over candidates, {dt:.1f} s",
+            "single_thread": single}
 
 
 def load_pmc_traffic():
