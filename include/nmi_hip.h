@@ -130,6 +130,15 @@ int nmi_search_grid_shard(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S_l
                           uint64_t *d_key, uint64_t *h_key);
 
 /*
+ * The same for any rectangular block of the grid: renders [s_offset, s_offset + S_local) x warps [w_offset, w_offset +
+ * Wn_local) of an S_total x Wn_total grid (used when there are fewer renders than ranks and the warp axis is sharded
+ * instead).  d_ratings (nullable) is [Wn_local][S_local]; the key carries the global linear index w * S_total + s.
+ */
+int nmi_search_grid_block(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S_local, int32_t s_offset, int32_t S_total,
+                          const uint8_t *warp_stack, int32_t Wn_local, int32_t w_offset, int32_t Wn_total, float *d_ratings,
+                          uint64_t *d_key, uint64_t *h_key);
+
+/*
  * Warp-stack producer: replaces Image::calculateWarping (Thirdparty/Localization/image.cpp:115-128),
  * i.e. Wn calls of cv::cuda::warpPerspective(frame, warped[w], M[w], size) with INTER_LINEAR / BORDER_CONSTANT 0.
  *   h_forward   host doubles [Wn][9], row-major 3x3 forward homographies K*R*K^-1 exactly as image.cpp:106 stores them

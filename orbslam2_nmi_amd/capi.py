@@ -23,7 +23,7 @@ ERR_NOT_READY = -4
 # Every symbol include/nmi_hip.h declares; tests check that the library exports all of them.
 EXPORTED_SYMBOLS = (
     "nmi_params_default", "nmi_create", "nmi_destroy", "nmi_set_stream", "nmi_synchronize", "nmi_eval_pair", "nmi_eval_pair_debug",
-    "nmi_search_grid", "nmi_search_grid_shard", "nmi_warp_homographies", "nmi_warp_stack", "nmi_render_mvp", "nmi_render_points", "nmi_level_create", "nmi_level_create_mesh", "nmi_level_run", "nmi_level_destroy", "nmi_texture_create",
+    "nmi_search_grid", "nmi_search_grid_shard", "nmi_search_grid_block", "nmi_warp_homographies", "nmi_warp_stack", "nmi_render_mvp", "nmi_render_points", "nmi_level_create", "nmi_level_create_mesh", "nmi_level_run", "nmi_level_destroy", "nmi_texture_create",
     "nmi_texture_destroy", "nmi_render_mesh", "nmi_stream_create", "nmi_stream_destroy",
     "nmi_stream_submit", "nmi_stream_wait", "nmi_key_pack", "nmi_key_unpack", "nmi_search_grid_rccl",
     "nmi_rccl_unique_id", "nmi_rccl_comm_init", "nmi_rccl_comm_destroy", "nmi_set_profiling", "nmi_last_kernel_ms",
@@ -79,6 +79,7 @@ def load_library(build_if_missing=False):
     lib.nmi_eval_pair_debug.argtypes = [vp, vp, vp, f32p, vp, vp, vp, vp]
     lib.nmi_search_grid.argtypes = [vp, vp, i32, vp, i32, vp, i64p, f32p]
     lib.nmi_search_grid_shard.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp, u64p]
+    lib.nmi_search_grid_block.argtypes = [vp, vp, i32, i32, i32, vp, i32, i32, i32, vp, vp, u64p]
     lib.nmi_warp_homographies.argtypes = [C.POINTER(C.c_double), C.POINTER(i32), f32p, C.POINTER(C.c_double)]
     lib.nmi_warp_stack.argtypes = [vp, vp, C.POINTER(C.c_double), i32, vp]
     lib.nmi_render_mvp.argtypes = [C.POINTER(RenderParams), f32p, f32p, f32p, f32p, f32p]
@@ -356,10 +357,12 @@ class NmiContext:
                     "nmi_search_grid")
         return int(idx.value), np.float32(sc.value)
 
-    def search_grid_shard(self, render_stack, s_offset, s_total, warp_stack, ratings=None, key_out=None, blocking=True):
+    def search_grid_shard(self, render_stack, s_offset, s_total, warp_stack, ratings=None, key_out=None, blocking=True,
+                          w_offset=0, wn_total=None):
         """One rank's part of a sharded search.  -> packed key (int) if blocking else None.
 
-        key_out: optional device int64/uint64 tensor of one element that receives the key (for a collective)."""
+        key_out: optional device int64/uint64 tensor of one element that receives the key (for a collective).
+        w_offset / wn_total: position of the given warps in the global warp axis when that axis is sharded too."""
         rs, ws = self._stack(render_stack, "render_stack"), self._stack(warp_stack, "warp_stack")
         S, Wn = rs.shape[0], ws.shape[0]
         rp = self._ratings_ptr(ratings, Wn, S)
@@ -369,9 +372,10 @@ class NmiContext:
                 raise TypeError("key_out must be a one-element 64-bit device tensor")
             kp = key_out.data_ptr()
         hk = C.c_uint64(0)
-        self._check(self._lib.nmi_search_grid_shard(self._h, rs.data_ptr(), S, int(s_offset), int(s_total), ws.data_ptr(),
-                                                    Wn, rp, kp, C.byref(hk) if blocking else None),
-                    "nmi_search_grid_shard")
+        self._check(self._lib.nmi_search_grid_block(self._h, rs.data_ptr(), S, int(s_offset), int(s_total), ws.data_ptr(),
+                                                    Wn, int(w_offset), int(Wn + w_offset if wn_total is None else wn_total), rp, kp,
+                                                    C.byref(hk) if blocking else None),
+                    "nmi_search_grid_block")
         return int(hk.value) if blocking else None
 
     def _ratings_ptr(self, ratings, Wn, S):

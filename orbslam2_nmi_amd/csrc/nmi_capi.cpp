@@ -70,7 +70,7 @@ int ensure_order(nmi_ctx *ctx, int S, int Wn)
 // Enqueues the grid kernel (one launch, nothing else).  No synchronisation.
 int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_offset, int S_total,
                  const uint8_t *warp_stack, int Wn, float *d_ratings, unsigned long long *out_key, bool post,
-                 uint32_t *dbg_joint, uint32_t *dbg_h1, uint32_t *dbg_h2, float *dbg_sums)
+                 uint32_t *dbg_joint, uint32_t *dbg_h1, uint32_t *dbg_h2, float *dbg_sums, int w_offset)
 {
     const nmi_params &p = ctx->params;
     nmi::GridArgs a{};
@@ -80,6 +80,7 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     a.Wn = Wn;
     a.s_offset = s_offset;
     a.S_total = S_total;
+    a.w_offset = w_offset;
     nmi::set_geometry(a, p.width, p.height, render_stack, warp_stack, p.render_bottom_up != 0);
     a.shift = ctx->shift;
     a.mode = p.mode;
@@ -461,11 +462,21 @@ int nmi_key_unpack(uint64_t key, int64_t *global_linear_index, float *score)
 int nmi_search_grid_shard(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S_local, int32_t s_offset, int32_t S_total,
                           const uint8_t *warp_stack, int32_t Wn, float *d_ratings, uint64_t *d_key, uint64_t *h_key)
 {
-    int rc = check_grid_args(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn);
+    return nmi_search_grid_block(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn, 0, Wn, d_ratings, d_key, h_key);
+}
+
+int nmi_search_grid_block(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S_local, int32_t s_offset, int32_t S_total,
+                          const uint8_t *warp_stack, int32_t Wn_local, int32_t w_offset, int32_t Wn_total, float *d_ratings,
+                          uint64_t *d_key, uint64_t *h_key)
+{
+    int rc = check_grid_args(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn_local);
     if (rc != NMI_OK) return rc;
+    if (w_offset < 0 || Wn_total < Wn_local || w_offset + Wn_local > Wn_total) return NMI_ERR_INVALID_ARGUMENT;
+    if ((int64_t)S_total * Wn_total >= 0x7FFFFFFFll) return NMI_ERR_UNSUPPORTED;  // index lives in 32 bits of the key
+    const int32_t Wn = Wn_local;
     DeviceGuard guard(ctx->device);
     rc = enqueue_grid(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn, d_ratings, (unsigned long long *)d_key,
-                      h_key != nullptr, nullptr, nullptr, nullptr, nullptr);
+                      h_key != nullptr, nullptr, nullptr, nullptr, nullptr, w_offset);
     if (rc != NMI_OK) return rc;
     if (h_key) {
         unsigned long long k = 0;

@@ -96,7 +96,7 @@ void build_order(int S, int Wn, int *order);
 int ensure_order(nmi_ctx *ctx, int S, int Wn);
 int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_offset, int S_total, const uint8_t *warp_stack, int Wn,
                  float *d_ratings, unsigned long long *out_key, bool post, uint32_t *dbg_joint, uint32_t *dbg_h1, uint32_t *dbg_h2,
-                 float *dbg_sums);
+                 float *dbg_sums, int w_offset = 0);
 int stage_floats(nmi_ctx *ctx, StagingRing &ring, const float *h_src, size_t n, float **d_out);
 int fetch_key(nmi_ctx *ctx, unsigned long long *key);
 int check_grid_args(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_offset, int S_total, const uint8_t *warp_stack,

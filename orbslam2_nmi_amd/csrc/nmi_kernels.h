@@ -21,6 +21,7 @@ struct GridArgs {
     const uint8_t *warp_stack;    // [Wn][H][W]
     int S_local, Wn;
     int s_offset, S_total;        // position of this shard in the global grid
+    int w_offset;                 // first warp of this shard in the global grid (0 unless the warp axis is sharded)
     int width, height, npix;
     int chunks_per_row;           // width / 16 when vec_ok
     uint32_t cpr_magic;           // ceil(2^32 / chunks_per_row)

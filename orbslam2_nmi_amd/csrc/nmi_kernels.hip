@@ -591,7 +591,7 @@ __device__ __forceinline__ void final_phase(Lds &lds, const GridArgs &a, int lan
         // (score bits, inverted global index) reproduces it; negative / NaN scores contribute nothing.
         if (score >= 0.0f) {
             const uint32_t bits = score == 0.0f ? 0u : __float_as_uint(score);
-            const uint32_t gidx = (uint32_t)w * (uint32_t)a.S_total + (uint32_t)(a.s_offset + s);
+            const uint32_t gidx = (uint32_t)(a.w_offset + w) * (uint32_t)a.S_total + (uint32_t)(a.s_offset + s);
             const unsigned long long key = ((unsigned long long)bits << 32) | (unsigned long long)(0xFFFFFFFFu - gidx);
             // returning form: the value is not needed, but its arrival (awaited once, at kernel end) proves the
             // max was performed, which the completion protocol below builds on

@@ -21,6 +21,17 @@ def render_shard(s_total, rank, world):
     return offset, count
 
 
+def grid_shard(s_total, wn_total, rank, world):
+    """Block of the S x Wn grid for `rank`: (s_offset, s_count, w_offset, w_count).  The render axis is sharded when it has at
+    least one render per rank (no render is then replicated); otherwise the warp axis, every rank holding all
+    renders.  With fewer than `world` cells on both axes the render axis is used and the surplus ranks get empty blocks."""
+    if s_total >= world or wn_total < world:
+        off, cnt = render_shard(s_total, rank, world)
+        return off, cnt, 0, wn_total
+    off, cnt = render_shard(wn_total, rank, world)
+    return 0, s_total, off, cnt
+
+
 def global_index(w, s_global, s_total):
     """Linear index of candidate (warp w, render s_global) in the unsharded rating table [Wn][S_total]."""
     return w * s_total + s_global
@@ -44,14 +55,14 @@ def sharded_search(ctx, render_shard_stack, s_offset, s_total, warp_stack, key_t
     return capi.key_unpack(int(key_tensor.item()))
 
 
-def local_key_from_ratings(ratings_local, s_offset, s_total):
-    """Host restatement of what the kernel's atomicMax computes, for ratings [Wn][S_local] of one shard.
+def local_key_from_ratings(ratings_local, s_offset, s_total, w_offset=0):
+    """Host restatement of what the kernel's atomicMax computes, for ratings [Wn_local][S_local] of one block.
     Used by the CPU (gloo) tests of the collective logic."""
     r = np.asarray(ratings_local, np.float32)
     best = 0
     wn, s_local = r.shape
     for w in range(wn):
         for s in range(s_local):
-            k = capi.key_pack(float(r[w, s]), global_index(w, s_offset + s, s_total))
+            k = capi.key_pack(float(r[w, s]), global_index(w_offset + w, s_offset + s, s_total))
             best = max(best, k)
     return best

@@ -361,6 +361,18 @@ def test_shard_keys_compose(nmi):
                 tabs.append(t)
             assert nmi.key_unpack(max(keys)) == (idx, best)
             assert torch.equal(torch.cat(tabs, dim=1), full)
+        # the warp axis sharded instead (fewer renders than ranks): blocks of warps, global indices through w_offset
+        for parts in (2, 3, 6):
+            n = 6 // parts
+            keys, tabs = [], []
+            for r in range(parts):
+                t = torch.zeros(n, 8, device="cuda")
+                keys.append(ctx.search_grid_shard(rs, 0, 8, ws[r * n:(r + 1) * n].contiguous(), t, w_offset=r * n, wn_total=6))
+                tabs.append(t)
+            assert nmi.key_unpack(max(keys)) == (idx, best)
+            assert torch.equal(torch.cat(tabs, dim=0), full)
+        with pytest.raises(nmi.NmiError):
+            ctx.search_grid_shard(rs, 0, 8, ws, w_offset=3, wn_total=6)  # block sticks out of the grid
 
 
 def test_reuse_of_one_context_is_clean(nmi):

@@ -27,6 +27,20 @@ def test_render_shard_partitions():
         sharding.render_shard(8, 8, 8)
 
 
+def test_grid_shard_picks_the_axis():
+    # enough renders: render axis, all warps everywhere
+    assert sharding.grid_shard(27, 27, 3, 8) == (12, 3, 0, 27)
+    assert sharding.grid_shard(512, 64, 3, 8) == (192, 64, 0, 64)
+    # fewer renders than ranks: warp axis, all renders everywhere
+    assert sharding.grid_shard(1, 27, 2, 8) == (0, 1, 8, 4)
+    blocks = [sharding.grid_shard(3, 27, r, 8) for r in range(8)]
+    assert all(b[:2] == (0, 3) for b in blocks) and sum(b[3] for b in blocks) == 27 and blocks[0][2] == 0
+    for (_, _, o1, c1), (_, _, o2, _) in zip(blocks, blocks[1:]):
+        assert o1 + c1 == o2
+    # tiny grid on both axes: render axis, surplus ranks empty
+    assert [sharding.grid_shard(2, 3, r, 4)[1] for r in range(4)] == [1, 1, 0, 0]
+
+
 WORKER = textwrap.dedent("""
     import os, sys
     import numpy as np, torch, torch.distributed as dist
@@ -42,21 +56,25 @@ WORKER = textwrap.dedent("""
         rs = rs.copy(); rs[7] = rs[wl["planted"] % 8]; rs[0] = rs[wl["planted"] % 8]
     if case == "allzero":    # constant renders: every score 0 -> winner index 0 (first exact zero)
         rs = np.full_like(rs, 255)
-    S = rs.shape[0]
-    off, cnt = sharding.render_shard(S, rank, world)
-    if cnt:
-        local, _, _ = oc.search_grid(rs[off:off + cnt], ws)
+    if case == "warpaxis":   # fewer renders than ranks: the warp axis is sharded instead (SURVEY.md 8e)
+        rs = rs[:world - 1] if world > 1 else rs[:1]
+    S, Wn = rs.shape[0], ws.shape[0]
+    off, cnt, woff, wcnt = sharding.grid_shard(S, Wn, rank, world)
+    assert (case == "warpaxis") == (wcnt != Wn or world == 1)
+    if cnt and wcnt:
+        local, _, _ = oc.search_grid(rs[off:off + cnt], ws[woff:woff + wcnt])
     else:
-        local = np.zeros((ws.shape[0], 0), np.float32)
-    key = torch.tensor([sharding.local_key_from_ratings(local, off, S)], dtype=torch.int64)
+        local = np.zeros((wcnt, cnt), np.float32)
+    key = torch.tensor([sharding.local_key_from_ratings(local, off, S, woff)], dtype=torch.int64)
     sharding.allreduce_key(key, dist)
     got = capi.key_unpack(int(key.item()))
     full, idx, best = oc.search_grid(rs, ws)
     assert got == (idx, best), (rank, got, idx, best)
-    # the gathered shards reassemble the full rating table (optional all-gather of SURVEY.md 8e)
+    # the gathered blocks reassemble the full rating table (optional all-gather of SURVEY.md 8e)
     parts = [None] * world
-    dist.all_gather_object(parts, (off, local))
-    table = np.concatenate([p[1] for p in sorted(parts, key=lambda p: p[0])], axis=1)
+    dist.all_gather_object(parts, (off, woff, local))
+    parts = sorted(parts, key=lambda p: (p[1], p[0]))
+    table = np.concatenate([p[2] for p in parts], axis=0 if case == "warpaxis" else 1)
     assert (table == full).all()
     dist.barrier(); dist.destroy_process_group()
     print("rank", rank, "ok", got)
@@ -69,7 +87,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,case", [(2, "planted"), (2, "ties"), (2, "allzero"), (3, "planted")])
+@pytest.mark.parametrize("world,case", [(2, "planted"), (2, "ties"), (2, "allzero"), (3, "planted"), (3, "warpaxis")])
 def test_sharded_argmax_over_gloo(world, case, tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
