@@ -212,13 +212,15 @@ def test_flat_regions_in_a_grid(nmi):
     ref = np.array([[oc.eval_pair(rs[s], ws[v]) for s in range(S)] for v in range(Wn)], np.float32)
     ibest, vbest = oc.find_max(ref)
     with nmi.NmiContext(w, h) as ctx:
-        for mask in (3, 7):
-            ctx.set_option(ctx.OPT_PHASE_MASK, mask)
-            ratings = torch.empty((Wn, S), dtype=torch.float32, device="cuda")
-            idx, val = ctx.search_grid(dev(rs), dev(ws), ratings=ratings)
-            got = ratings.cpu().numpy()
-            assert np.abs(got - ref).max() <= SCORE_TOL, mask
-            assert idx == ibest and abs(val - float(vbest)) <= SCORE_TOL, mask
+        for variant in (3, 0, 1, 4):       # every wrap-handling variant meets the flat regions, with and without folding
+            ctx.set_option(ctx.OPT_HIST_VARIANT, variant)
+            for mask in ((3,) if variant == 4 else (3, 7)):  # bit 2 is a different ablation switch in the pipelined kernel
+                ctx.set_option(ctx.OPT_PHASE_MASK, mask)
+                ratings = torch.full((Wn, S), -3.0, dtype=torch.float32, device="cuda")
+                idx, val = ctx.search_grid(dev(rs), dev(ws), ratings=ratings)
+                got = ratings.cpu().numpy()
+                assert np.abs(got - ref).max() <= SCORE_TOL, (variant, mask)
+                assert idx == ibest and abs(val - float(vbest)) <= SCORE_TOL, (variant, mask)
 
 
 def test_grid_golden(nmi, golden_grid):
