@@ -13,6 +13,7 @@
 // against the warp stack of a 1x1x3 grid.  Exit code 0 iff both recover what was planted.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -221,6 +222,45 @@ int main()
                               42u);
     printf("shim NMIWithCuda_noMask(render 0, warp 2) = %.7f, grid rating = %.7f\n", nmi_shim, table[2]);
     ok = ok && nmi_shim == table[2];
+
+    // ---- part C: throughput of the UNCHANGED per-candidate call site (src/Tracking.cc:1886-1894) at the north-star frame
+    // size: 640x480, one blocking CUDAF::NMIWithCuda_noMask per candidate, score on the host after every call.
+    {
+        const int w = 640, h = 480, n_r = 3, n_w = 9;
+        std::vector<uint8_t> img((size_t)w * h * (n_r + n_w));
+        unsigned s = 777u;
+        for (size_t k = 0; k < img.size(); ++k) {
+            s = s * 1664525u + 1013904223u;
+            const size_t pix = k % ((size_t)w * h);
+            const float base = 128.0f + 60.0f * sinf(0.02f * (float)(pix % w)) * cosf(0.015f * (float)(pix / w));
+            img[k] = (uint8_t)fminf(fmaxf(base + (float)((s >> 16) & 31) - 16.0f + 3.0f * (float)(k / ((size_t)w * h)), 0.0f), 255.0f);
+        }
+        uint8_t *d_img = nullptr;
+        CHECK_HIP(hipMalloc((void **)&d_img, img.size()));
+        CHECK_HIP(hipMemcpy(d_img, img.data(), img.size(), hipMemcpyHostToDevice));
+        for (int r = 0; r < n_r; ++r) CUDAF::RegisterRenderBuffer(100u + r, d_img + (size_t)r * w * h);
+        std::vector<float> first(n_r * n_w), again(n_r * n_w);
+        auto pass = [&](std::vector<float> &outv) {
+            for (int r = 0; r < n_r; ++r)
+                for (int v = 0; v < n_w; ++v)
+                    CUDAF::NMIWithCuda_noMask((cv::cuda::PtrStep<unsigned char> *)(d_img + (size_t)(n_r + v) * w * h), SUC, MATCHING_NMI, w, h,
+                                              &outv[r * n_w + v], 100u + r);
+        };
+        pass(first);  // warm-up (context creation for this frame size)
+        const int reps = 150;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < reps; ++k) pass(again);
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const double rate = (double)reps * n_r * n_w / dt;
+        bool same = true, distinct = false;
+        for (size_t k = 0; k < first.size(); ++k) same = same && first[k] == again[k] && first[k] > 0.0f && first[k] < 1.0f;
+        for (size_t k = 1; k < first.size(); ++k) distinct = distinct || first[k] != first[0];
+        printf("shim call site: %d blocking NMIWithCuda_noMask calls at %dx%d: %.1f us per call = %.0f evals/s (target 50000)\n",
+               reps * n_r * n_w, w, h, dt / (reps * n_r * n_w) * 1e6, rate);
+        printf("SHIM_EVALS_PER_S %.0f\n", rate);
+        ok = ok && same && distinct;
+        (void)hipFree(d_img);
+    }
     (void)hipFree(d_rot);
     CUDAF::Shutdown();
     (void)hipFree(d.d_frame);

@@ -60,7 +60,7 @@ typedef struct nmi_params {
     int32_t use_bg;           /* nmi_prop_BG (Thirdparty/Localization/allProperties.hpp:38); default 1 */
     int32_t render_bottom_up; /* 1 = vertical flip of the render as in NMI.cu:82; default 1 */
     int32_t device;           /* HIP device ordinal; -1 = the calling thread's current device */
-    int32_t max_candidates;   /* capacity hint for the internal ratings buffer; grown on demand */
+    int32_t max_candidates;   /* ignored (kept for ABI compatibility): rating tables are caller-owned */
     void *stream;             /* hipStream_t to run on; NULL = the context creates its own */
     int32_t reserved[8];      /* must be 0 */
 } nmi_params;
@@ -105,12 +105,14 @@ int nmi_eval_pair_debug(nmi_ctx *ctx, const uint8_t *render, const uint8_t *warp
  * (src/Tracking.cc:1879-1902: S renders x Wn warps calls of NMIWithCuda_noMask) and
  * helperFunctions::find_max_elements + the caller's [0] pick (helperFunctions.cpp:50-103,
  * Tracking.cc:1905,1952-1953).
- *   d_ratings       device float [Wn*S] or NULL (an internal buffer is used).
+ *   d_ratings       device float [Wn*S], or NULL when only the winner is wanted (no rating table is stored then).
  *   h_best_index    linear index w*S + s of the winner: max starts at 0, strict '>', lowest index
  *                   among cells equal to the max; -1 if no cell qualifies (every score negative or
  *                   NaN, where the reference indexes an empty vector).
  *   h_best_score    the winner's score.
- * Blocking (8-byte read-back of the packed winner).
+ * Blocking (8-byte read-back of the packed winner).  With the default result path the call returns when the kernel's
+ * last workgroup has posted the winner to pinned host memory; when d_ratings is given it additionally waits for the
+ * context's stream, so the table is complete and visible to every stream when the call returns.
  */
 int nmi_search_grid(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S, const uint8_t *warp_stack, int32_t Wn,
                     float *d_ratings, int64_t *h_best_index, float *h_best_score);
@@ -232,12 +234,17 @@ uint64_t nmi_key_pack(float score, int64_t global_linear_index);
 int nmi_key_unpack(uint64_t key, int64_t *global_linear_index, float *score);
 
 /*
- * RCCL form: nmi_search_grid_shard followed by ncclAllReduce(ncclMax, ncclUint64) of the key on the
- * context's stream over `nccl_comm` (an ncclComm_t created by the caller), then the 8-byte read-back.
+ * RCCL form: nmi_search_grid_shard / _block followed by ncclAllReduce(ncclMax, ncclUint64) of the key on the context's
+ * stream over `nccl_comm` (an ncclComm_t created by the caller), then the 8-byte read-back.  A rank whose block is
+ * empty (S_local == 0 or Wn_local == 0: fewer renders than ranks on a render-sharded level) contributes "no candidate"
+ * and still takes part in the collective.  The _block form shards either axis (see nmi_search_grid_block).
  */
 int nmi_search_grid_rccl(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S_local, int32_t s_offset,
                          int32_t S_total, const uint8_t *warp_stack, int32_t Wn, float *d_ratings,
                          void *nccl_comm, int64_t *h_best_index, float *h_best_score);
+int nmi_search_grid_block_rccl(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S_local, int32_t s_offset, int32_t S_total,
+                               const uint8_t *warp_stack, int32_t Wn_local, int32_t w_offset, int32_t Wn_total, float *d_ratings,
+                               void *nccl_comm, int64_t *h_best_index, float *h_best_score);
 
 /* Communicator bootstrap for hosts that have no ncclComm_t yet: rank 0 calls nmi_rccl_unique_id and
  * ships the 128 bytes to the other ranks by any means; every rank then calls nmi_rccl_comm_init. */
@@ -257,9 +264,10 @@ int nmi_last_kernel_ms(nmi_ctx *ctx, float *h_ms);
  * Tuning / ablation knobs (defaults are the shipped configuration; results stay exact for every value
  * except NMI_OPT_HIST_VARIANT = 2, which skips the counter-wrap bookkeeping, and a partial phase mask).
  */
-#define NMI_OPT_HIST_VARIANT 1 /* 0 per-pixel wrap test, 1 batched wrap test, 2 unchecked, 3 optimistic + verify + exact redo
-                                  (default), 4 = 3 with histogram and decode overlapped by wavefront role (experimental:
-                                  exact, but measured slower than 3 -- DESIGN.md section 4) */
+#define NMI_OPT_HIST_VARIANT 1 /* 3 optimistic + verify + exact redo (default), 1 exact wrap bookkeeping throughout.  The
+                                  experiments 0 (per-pixel wrap test), 2 (unchecked) and 4 (histogram and decode overlapped by
+                                  wavefront role; exact but slower) exist only in a library built with
+                                  -DNMI_BUILD_ABLATIONS (NMI_ERR_UNSUPPORTED otherwise). */
 #define NMI_OPT_PHASE_MASK 2   /* bit 0 histogram phase, bit 1 decode + score, bit 2 disable the flat-chunk shortcut; default 3 */
 #define NMI_OPT_WORKGROUPS 3   /* workgroups per launch; 0 = one per compute unit (default) */
 #define NMI_OPT_RESULT_PATH 4  /* how the 8-byte winner reaches the host: 1 the kernel posts it to pinned host memory
@@ -269,9 +277,21 @@ int nmi_last_kernel_ms(nmi_ctx *ctx, float *h_ms);
 #define NMI_OPT_TILE_QUEUE 6   /* mesh renderer: capacity (work items) of the queue that hands large triangles to the
                                   tile pass, at most 4194304 (default); 0 = every triangle is shaded by its own lane.
                                   Same image for every value (small values exercise the overflow path in tests). */
+#define NMI_OPT_SPLIT 7        /* small grids (nmi_eval_pair, collapsed search levels): K workgroups per candidate, each owning
+                                  256 / K rows of the joint histogram (no merge; bit-identical results).  -1 (default): the
+                                  largest K of 8 / 4 / 2 with candidates * K <= compute units, none for larger grids; 0: never;
+                                  2 / 4 / 8: that K whenever the grid fits. */
+#define NMI_OPT_WAIT_MODE 8    /* how a blocking call waits for the posted result: 0 (default) spins on the pinned word
+                                  (lowest latency, occupies the calling core for the search), 1 yields the core between
+                                  polls (sched_yield; for hosts whose other threads need the core, e.g. ORB-SLAM2's
+                                  LocalMapping / LoopClosing).  NMI_OPT_RESULT_PATH 0 sleeps in hipStreamSynchronize instead. */
 int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value);
 
 /* Introspection. */
+/* Copies the context's per-count term table, term[c] = (c/len) * log2(c/len) in the reference's fp32 form with
+ * len = width * height (ComputeEntropyKernel, NMI.cu:242-263; term[0] = 0), c = 0..len, to host memory.
+ * n must be width * height + 1.  Blocking.  Lets a test compare every entry with its oracle. */
+int nmi_copy_term_table(nmi_ctx *ctx, float *h_out, int64_t n);
 int nmi_abi_version(void);
 const char *nmi_error_string(int code);
 const char *nmi_last_error_detail(nmi_ctx *ctx); /* text of the last failing HIP/RCCL call, or "" */

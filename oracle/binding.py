@@ -46,8 +46,42 @@ def lib():
         l.nmi_oracle_search_grid.argtypes = [_u8p, C.c_int, _u8p, C.c_int] + [C.c_int] * 7 + [_f32p, _f32p]
         l.nmi_oracle_search_grid.restype = C.c_int64
         l.nmi_oracle_max_threads.restype = C.c_int
+        l.nmi_oracle_set_term_mode.argtypes = [C.c_int]
+        l.nmi_oracle_set_term_mode.restype = None
+        l.nmi_oracle_get_term_mode.restype = C.c_int
+        l.nmi_oracle_term_table.argtypes = [C.c_int, _f32p]
+        l.nmi_oracle_term_table.restype = None
         _lib = l
     return _lib
+
+
+TERM_LIBM, TERM_ROUNDED = 0, 1
+
+
+class term_mode:
+    """with term_mode(TERM_ROUNDED): ...  -- per-bin log2 evaluated as the correctly rounded fp32 value (see
+    nmi_oracle_bin_term); the default TERM_LIBM is the host libm's log2f."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = lib().nmi_oracle_get_term_mode()
+        lib().nmi_oracle_set_term_mode(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        lib().nmi_oracle_set_term_mode(self.prev)
+
+
+def rounded():
+    return term_mode(TERM_ROUNDED)
+
+
+def term_table(length):
+    out = np.zeros(int(length) + 1, np.float32)
+    lib().nmi_oracle_term_table(int(length), out.ctypes.data_as(_f32p))
+    return out
 
 
 def _u8(a):

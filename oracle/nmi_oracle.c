@@ -83,14 +83,36 @@ void nmi_oracle_joint_hist(const uint8_t *render, const uint8_t *warped, int wid
  * Per-bin term, ComputeEntropyKernel, NMI.cu:242-263:
  *   0 when the count is 0, else ((float)c / (float)length) * log2f((float)c / (float)length).
  * length is always width*height (kernel.cu:85), also when BG pixels were skipped.
+ *
+ * log2f is a library function whose last bit differs between implementations: CUDA documents its device log2f as
+ * within 1 ulp, glibc's is within 1 ulp, and neither is the reference's build.  Two evaluations are offered:
+ *   NMI_ORACLE_TERM_LIBM (0, default)      l = log2f(p) of this host's libm -- the expression as written;
+ *   NMI_ORACLE_TERM_ROUNDED (1)            l = (float)log2((double)p): the fp64 logarithm rounded once, i.e. the
+ *                                          correctly rounded fp32 log2 (what any 1-ulp log2f approximates, and what
+ *                                          the product's per-count table holds, csrc/nmi_kernels.hip nmi_table_kernel).
+ * With mode 1 the oracle and the GPU evaluate identical fp32 operations in identical order, so rating tables are
+ * compared with ==; mode 0 stays as the <= 1e-5 cross-check of the north_star's tolerance.
  */
+#define NMI_ORACLE_TERM_LIBM 0
+#define NMI_ORACLE_TERM_ROUNDED 1
+static int g_term_mode = NMI_ORACLE_TERM_LIBM;
+
+void nmi_oracle_set_term_mode(int mode) { g_term_mode = mode == NMI_ORACLE_TERM_ROUNDED ? NMI_ORACLE_TERM_ROUNDED : NMI_ORACLE_TERM_LIBM; }
+int nmi_oracle_get_term_mode(void) { return g_term_mode; }
+
 float nmi_oracle_bin_term(uint32_t count, int length)
 {
     if (count == 0)
         return 0.0f;
     float p = (float)count / (float)length;
-    float l = log2f(p);
+    float l = g_term_mode == NMI_ORACLE_TERM_ROUNDED ? (float)log2((double)p) : log2f(p);
     return p * l;
+}
+
+/* The whole per-count table term[c], c = 0..length, in the current mode (to compare with the product's table). */
+void nmi_oracle_term_table(int length, float *out /*[length + 1]*/)
+{
+    for (int c = 0; c <= length; ++c) out[c] = nmi_oracle_bin_term((uint32_t)c, length);
 }
 
 /*

@@ -25,9 +25,9 @@ EXPORTED_SYMBOLS = (
     "nmi_params_default", "nmi_create", "nmi_destroy", "nmi_set_stream", "nmi_synchronize", "nmi_eval_pair", "nmi_eval_pair_debug",
     "nmi_search_grid", "nmi_search_grid_shard", "nmi_search_grid_block", "nmi_warp_homographies", "nmi_warp_stack", "nmi_render_mvp", "nmi_render_points", "nmi_level_create", "nmi_level_create_mesh", "nmi_level_run", "nmi_level_destroy", "nmi_texture_create",
     "nmi_texture_destroy", "nmi_render_mesh", "nmi_stream_create", "nmi_stream_destroy",
-    "nmi_stream_submit", "nmi_stream_wait", "nmi_key_pack", "nmi_key_unpack", "nmi_search_grid_rccl",
+    "nmi_stream_submit", "nmi_stream_wait", "nmi_key_pack", "nmi_key_unpack", "nmi_search_grid_rccl", "nmi_search_grid_block_rccl",
     "nmi_rccl_unique_id", "nmi_rccl_comm_init", "nmi_rccl_comm_destroy", "nmi_set_profiling", "nmi_last_kernel_ms",
-    "nmi_set_option", "nmi_abi_version", "nmi_error_string", "nmi_last_error_detail", "nmi_get_info",
+    "nmi_set_option", "nmi_copy_term_table", "nmi_abi_version", "nmi_error_string", "nmi_last_error_detail", "nmi_get_info",
 )
 
 
@@ -99,12 +99,14 @@ def load_library(build_if_missing=False):
     lib.nmi_key_pack.restype = C.c_uint64
     lib.nmi_key_unpack.argtypes = [C.c_uint64, i64p, f32p]
     lib.nmi_search_grid_rccl.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp, i64p, f32p]
+    lib.nmi_search_grid_block_rccl.argtypes = [vp, vp, i32, i32, i32, vp, i32, i32, i32, vp, vp, i64p, f32p]
     lib.nmi_rccl_unique_id.argtypes = [C.POINTER(C.c_uint8)]
     lib.nmi_rccl_comm_init.argtypes = [vp, C.POINTER(C.c_uint8), i32, i32, C.POINTER(vp)]
     lib.nmi_rccl_comm_destroy.argtypes = [vp]
     lib.nmi_set_option.argtypes = [vp, i32, C.c_int64]
     lib.nmi_set_profiling.argtypes = [vp, i32]
     lib.nmi_last_kernel_ms.argtypes = [vp, f32p]
+    lib.nmi_copy_term_table.argtypes = [vp, f32p, C.c_int64]
     lib.nmi_error_string.argtypes = [C.c_int]
     lib.nmi_error_string.restype = C.c_char_p
     lib.nmi_last_error_detail.argtypes = [vp]
@@ -165,6 +167,9 @@ class NmiContext:
     """nmi_ctx wrapper.  Mirrors the per-search objects of the reference (NmiObjects' buffers +
     the CUDA scratch of kernel.cu:59-73) as one persistent workspace."""
 
+    # {option: value} applied to every new context (tests use it to run whole suites with one kernel selection)
+    default_options = {}
+
     def __init__(self, width, height, bins=256, mode=MODE_SUC, use_bg=True, render_bottom_up=True, device=None,
                  stream=None, max_candidates=0):
         import torch
@@ -187,6 +192,8 @@ class NmiContext:
         if rc != NMI_OK:
             self._h = C.c_void_p()
             raise NmiError(rc, "nmi_create")
+        for opt, val in type(self).default_options.items():
+            self.set_option(opt, val)
 
     # -- plumbing -------------------------------------------------------------------------------
     def _check(self, rc, what):
@@ -230,6 +237,7 @@ class NmiContext:
             cur.synchronize()
 
     OPT_HIST_VARIANT, OPT_PHASE_MASK, OPT_WORKGROUPS, OPT_RESULT_PATH, OPT_XCD_TILING, OPT_TILE_QUEUE = 1, 2, 3, 4, 5, 6
+    OPT_SPLIT, OPT_WAIT_MODE = 7, 8
 
     def set_option(self, option, value):
         self._check(self._lib.nmi_set_option(self._h, int(option), int(value)), "nmi_set_option")
@@ -250,6 +258,13 @@ class NmiContext:
         self._check(self._lib.nmi_get_info(self._h, C.byref(cu), C.byref(wg), C.byref(lds)), "nmi_get_info")
         return {"compute_units": cu.value, "workgroups_per_launch": wg.value, "lds_bytes": lds.value}
 
+    def term_table(self):
+        """The per-count entropy-term table (NMI.cu:242-263 evaluated once per possible count) as numpy float32 [W*H+1]."""
+        out = np.zeros(self.width * self.height + 1, np.float32)
+        self._check(self._lib.nmi_copy_term_table(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), out.size),
+                    "nmi_copy_term_table")
+        return out
+
     def _img(self, t, what):
         t = _dev_u8(t, 2, what)
         if tuple(t.shape) != (self.height, self.width):
@@ -267,6 +282,7 @@ class NmiContext:
         """CUDAF::NMIWithCuda_noMask (kernel.cu:49-114) for one (render, warped frame) pair -> float32 score."""
         r, w = self._img(render, "render"), self._img(warped, "warped")
         out = C.c_float(0)
+        self._order_after_torch()
         self._check(self._lib.nmi_eval_pair(self._h, r.data_ptr(), w.data_ptr(), C.byref(out)), "nmi_eval_pair")
         return np.float32(out.value)
 
@@ -353,6 +369,7 @@ class NmiContext:
         S, Wn = rs.shape[0], ws.shape[0]
         rp = self._ratings_ptr(ratings, Wn, S)
         idx, sc = C.c_int64(0), C.c_float(0)
+        self._order_after_torch()  # the stacks (and a pre-filled ratings tensor) may come from torch's stream
         self._check(self._lib.nmi_search_grid(self._h, rs.data_ptr(), S, ws.data_ptr(), Wn, rp, C.byref(idx), C.byref(sc)),
                     "nmi_search_grid")
         return int(idx.value), np.float32(sc.value)
@@ -372,6 +389,7 @@ class NmiContext:
                 raise TypeError("key_out must be a one-element 64-bit device tensor")
             kp = key_out.data_ptr()
         hk = C.c_uint64(0)
+        self._order_after_torch()
         self._check(self._lib.nmi_search_grid_block(self._h, rs.data_ptr(), S, int(s_offset), int(s_total), ws.data_ptr(),
                                                     Wn, int(w_offset), int(Wn + w_offset if wn_total is None else wn_total), rp, kp,
                                                     C.byref(hk) if blocking else None),
@@ -394,13 +412,16 @@ class NmiContext:
         self._check(self._lib.nmi_rccl_comm_init(self._h, buf, rank, nranks, C.byref(comm)), "nmi_rccl_comm_init")
         return comm
 
-    def search_grid_rccl(self, render_stack, s_offset, s_total, warp_stack, comm, ratings=None):
+    def search_grid_rccl(self, render_stack, s_offset, s_total, warp_stack, comm, ratings=None, w_offset=0, wn_total=None):
+        """One rank's block of a sharded search + the RCCL MAX all-reduce of the packed winner -> global (index, score)."""
         rs, ws = self._stack(render_stack, "render_stack"), self._stack(warp_stack, "warp_stack")
         S, Wn = rs.shape[0], ws.shape[0]
         idx, sc = C.c_int64(0), C.c_float(0)
-        self._check(self._lib.nmi_search_grid_rccl(self._h, rs.data_ptr(), S, int(s_offset), int(s_total), ws.data_ptr(),
-                                                   Wn, self._ratings_ptr(ratings, Wn, S), comm, C.byref(idx),
-                                                   C.byref(sc)), "nmi_search_grid_rccl")
+        self._order_after_torch()
+        self._check(self._lib.nmi_search_grid_block_rccl(self._h, rs.data_ptr(), S, int(s_offset), int(s_total), ws.data_ptr(),
+                                                         Wn, int(w_offset), int(Wn + w_offset if wn_total is None else wn_total),
+                                                         self._ratings_ptr(ratings, Wn, S), comm, C.byref(idx), C.byref(sc)),
+                    "nmi_search_grid_block_rccl")
         return int(idx.value), np.float32(sc.value)
 
 

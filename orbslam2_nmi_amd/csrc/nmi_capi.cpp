@@ -4,6 +4,8 @@
 // and the candidate loop + arg-max of Tracking::RelocalizeWithNMI (src/Tracking.cc:1879-1905,1952):
 // a persistent context owns every buffer, one launch scores a whole candidate grid, and the only
 // host<->device traffic per search is one 8-byte key.
+#include <sched.h>
+
 #include "nmi_ctx.h"
 
 namespace nmi_internal {
@@ -20,17 +22,6 @@ int hip_fail(nmi_ctx *ctx, hipError_t e, const char *what)
 
 
 
-int ensure_ratings(nmi_ctx *ctx, int64_t n)
-{
-    if (n <= ctx->ratings_cap) return NMI_OK;
-    if (ctx->ratings) NMI_HIP_TRY(ctx, hipFree(ctx->ratings));
-    ctx->ratings = nullptr;
-    ctx->ratings_cap = 0;
-    NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->ratings, (size_t)n * sizeof(float)));
-    ctx->ratings_cap = n;
-    return NMI_OK;
-}
-
 // Visiting order of the candidates of an S x Wn grid: tiles of kTileW warps x kTileS renders (32 candidates = the
 // 32 workgroups one XCD runs at a time), tile after tile; within a tile render-fastest.  Cached per grid shape.
 void build_order(int S, int Wn, int *order)
@@ -43,34 +34,76 @@ void build_order(int S, int Wn, int *order)
                 for (int s = s0; s < s0 + tile_s && s < S; ++s) order[o++] = w * S + s;
 }
 
-int ensure_order(nmi_ctx *ctx, int S, int Wn)
+// The cached visiting order for this grid shape (device pointer in *d_order), built and uploaded on first use.  Never
+// synchronises the stream on a hit or on a miss with a free entry; only evicting the least recently used of kOrderCache
+// shapes waits (its table may still be read by a kernel in flight).
+int ensure_order(nmi_ctx *ctx, int S, int Wn, const int **d_order)
 {
+    *d_order = nullptr;
     if (!ctx->xcd_tiling) return NMI_OK;
-    if (ctx->order_S == S && ctx->order_Wn == Wn) return NMI_OK;
     const int64_t total = (int64_t)S * Wn;
-    if (total > ctx->order_cap) {
-        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->d_order) NMI_HIP_TRY(ctx, hipFree(ctx->d_order));
-        if (ctx->h_order) NMI_HIP_TRY(ctx, hipHostFree(ctx->h_order));
-        ctx->d_order = ctx->h_order = nullptr;
-        ctx->order_cap = 0;
-        NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_order, (size_t)total * sizeof(int)));
-        NMI_HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_order, (size_t)total * sizeof(int), hipHostMallocDefault));
-        ctx->order_cap = total;
-    } else {
-        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the staging copy may still feed an earlier upload
+    nmi_ctx::OrderEntry *victim = nullptr;
+    for (auto &e : ctx->orders) {
+        if (e.S == S && e.Wn == Wn) {
+            e.last_use = ++ctx->order_clock;
+            *d_order = e.d;
+            return NMI_OK;
+        }
+        if (!victim || (e.d == nullptr && victim->d != nullptr) || ((e.d == nullptr) == (victim->d == nullptr) && e.last_use < victim->last_use))
+            victim = &e;
     }
-    build_order(S, Wn, ctx->h_order);
-    NMI_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order, ctx->h_order, (size_t)total * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    ctx->order_S = S;
-    ctx->order_Wn = Wn;
+    nmi_ctx::OrderEntry &e = *victim;
+    if (e.d) NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // eviction: the old table / staging copy may be in use
+    if (total > e.cap) {
+        if (e.d) NMI_HIP_TRY(ctx, hipFree(e.d));
+        if (e.h) NMI_HIP_TRY(ctx, hipHostFree(e.h));
+        e.d = e.h = nullptr;
+        e.cap = 0;
+        e.S = e.Wn = -1;
+        NMI_HIP_TRY(ctx, hipMalloc((void **)&e.d, (size_t)total * sizeof(int)));
+        NMI_HIP_TRY(ctx, hipHostMalloc((void **)&e.h, (size_t)total * sizeof(int), hipHostMallocDefault));
+        e.cap = total;
+    }
+    build_order(S, Wn, e.h);
+    NMI_HIP_TRY(ctx, hipMemcpyAsync(e.d, e.h, (size_t)total * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    e.S = S;
+    e.Wn = Wn;
+    e.last_use = ++ctx->order_clock;
+    *d_order = e.d;
+    return NMI_OK;
+}
+
+// How many parts the split kernel should cut each candidate into for a launch of `total` candidates on `cap`
+// workgroups: the largest of 8 / 4 / 2 whose units all run at once, 0 = use the one-workgroup-per-candidate kernel.
+static int choose_split(const nmi_ctx *ctx, int64_t total, int cap)
+{
+    if (ctx->hist_variant != 3 || ctx->split_mode == 0 || total <= 0) return 0;
+    if (ctx->split_mode > 0) return nmi::split_workgroups((int)total, ctx->split_mode) <= cap ? ctx->split_mode : 0;
+    for (int k = 8; k >= 2; k >>= 1)
+        if (total * k <= cap && nmi::split_workgroups((int)total, k) <= ((cap + 7) & ~7)) return k;
+    return 0;
+}
+
+static int ensure_slabs(nmi_ctx *ctx, int n)
+{
+    if (n <= ctx->slab_cap) return NMI_OK;
+    if (ctx->d_slabs) {
+        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        NMI_HIP_TRY(ctx, hipFree(ctx->d_slabs));
+        ctx->d_slabs = nullptr;
+        ctx->slab_cap = 0;
+    }
+    const int cap = n > 128 ? n : 128;
+    NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_slabs, (size_t)cap * sizeof(nmi::SplitSlab)));
+    NMI_HIP_TRY(ctx, hipMemsetAsync(ctx->d_slabs, 0, (size_t)cap * sizeof(nmi::SplitSlab), ctx->stream));  // tickets start at 0
+    ctx->slab_cap = cap;
     return NMI_OK;
 }
 
 // Enqueues the grid kernel (one launch, nothing else).  No synchronisation.
 int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_offset, int S_total,
                  const uint8_t *warp_stack, int Wn, float *d_ratings, unsigned long long *out_key, bool post,
-                 uint32_t *dbg_joint, uint32_t *dbg_h1, uint32_t *dbg_h2, float *dbg_sums, int w_offset)
+                 uint32_t *dbg_joint, uint32_t *dbg_h1, uint32_t *dbg_h2, float *dbg_sums, int w_offset, bool post_score)
 {
     const nmi_params &p = ctx->params;
     nmi::GridArgs a{};
@@ -87,23 +120,19 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     a.table = ctx->table;
     a.scratch = ctx->d_scratch;
     a.order = nullptr;
-    if (ctx->xcd_tiling && (int64_t)S_local * Wn > 0 && (int64_t)S_local * Wn <= (1ll << 24)) {  // 4 B per candidate
-        const int orc = ensure_order(ctx, S_local, Wn);
-        if (orc != NMI_OK) return orc;
-        a.order = ctx->d_order;
-    }
     a.ratings = d_ratings;
     a.key = ctx->d_keys + ctx->slot;
     a.reset_key = ctx->d_keys + (ctx->slot ^ 1);
     a.out_key = out_key;
     a.done = ctx->d_done;
     // Only launches whose winner the host will poll for post to the mailbox (one bit of sequence is enough
-    // because those calls are blocking, hence strictly alternating).
+    // because those calls are blocking, hence strictly alternating).  The sequence numbers, the key-slot flip and the
+    // "posted" flag are committed only once the launch has been accepted: a failed launch leaves the protocol in step.
     post = post && ctx->result_path == 1;
+    post_score = post_score && ctx->result_path == 1;
     a.mailbox = post ? ctx->mailbox : nullptr;
-    a.seq = post ? ++ctx->seq : 0;
-    ctx->posted = post;
-    ctx->last_slot = ctx->slot;
+    a.score_post = post_score ? ctx->score_mailbox : nullptr;
+    a.seq = post ? ctx->seq + 1 : (post_score ? ctx->pair_seq + 1 : 0);
     a.dbg_joint = dbg_joint;
     a.dbg_h1 = dbg_h1;
     a.dbg_h2 = dbg_h2;
@@ -113,16 +142,33 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
 
     const int64_t total = (int64_t)S_local * Wn;
     if (total == 0) {
-        // nothing to score: the winner is "none" (key 0); publish it the way the kernel would
+        // nothing to score: the winner is "none" (key 0); publish it the way the kernel would.  The key slot keeps its
+        // "zero on entry" state for the next launch (nothing ever writes a winner into a ping-pong slot from outside:
+        // the RCCL form reduces into ctx->d_reduced_key).
         if (out_key) NMI_HIP_TRY(ctx, hipMemsetAsync(out_key, 0, sizeof(unsigned long long), ctx->stream));
         NMI_HIP_TRY(ctx, hipMemsetAsync(ctx->d_keys + ctx->slot, 0, sizeof(unsigned long long), ctx->stream));
         NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (post) ctx->mailbox->word = (unsigned long long)(ctx->seq & 1u) << 63;
+        if (post) {
+            ++ctx->seq;
+            ctx->mailbox->word = (unsigned long long)(ctx->seq & 1u) << 63;
+        }
+        ctx->posted = post;
+        ctx->last_slot = ctx->slot;
         return NMI_OK;
     }
-    ctx->slot ^= 1;
     const int cap = ctx->workgroups > 0 ? ctx->workgroups : ctx->compute_units;
-    const int workgroups = (int)(total < cap ? total : cap);
+    const int parts = choose_split(ctx, total, cap);
+    int workgroups = (int)(total < cap ? total : cap);
+    if (parts) {
+        const int rs = ensure_slabs(ctx, (int)total);
+        if (rs != NMI_OK) return rs;
+        a.slabs = ctx->d_slabs;
+        workgroups = nmi::split_workgroups((int)total, parts);
+    } else if (ctx->xcd_tiling && total <= (1ll << 24)) {  // 4 B per candidate
+        const int orc = ensure_order(ctx, S_local, Wn, &a.order);
+        if (orc != NMI_OK) return orc;
+    }
+#ifdef NMI_BUILD_ABLATIONS
     if (ctx->hist_variant == 4 && workgroups > ctx->scratch_workgroups) {
         NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->d_scratch) NMI_HIP_TRY(ctx, hipFree(ctx->d_scratch));
@@ -133,8 +179,19 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
         ctx->scratch_workgroups = alloc;
         a.scratch = ctx->d_scratch;
     }
+#endif
     if (ctx->profiling) NMI_HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
-    NMI_HIP_TRY(ctx, nmi::launch_grid(a, workgroups, p.use_bg != 0, ctx->stream));
+    if (parts)
+        NMI_HIP_TRY(ctx, nmi::launch_split(a, parts, workgroups, p.use_bg != 0, ctx->stream));
+    else
+        NMI_HIP_TRY(ctx, nmi::launch_grid(a, workgroups, p.use_bg != 0, ctx->stream));
+    // accepted: commit the protocol state
+    if (post) ++ctx->seq;
+    if (post_score) ++ctx->pair_seq;
+    ctx->posted = post;
+    ctx->last_slot = ctx->slot;
+    ctx->slot ^= 1;
+    ctx->last_parts = parts;
     if (ctx->profiling) {
         NMI_HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
         ctx->have_timing = true;
@@ -142,30 +199,45 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     return NMI_OK;
 }
 
+// Polls a pinned host word until (word & mask) == want; *out receives the word.  NMI_OPT_WAIT_MODE 0 spins (lowest
+// latency; occupies the calling core for the duration of the search), 1 yields the core between polls (the Tracking
+// thread shares the host with LocalMapping / LoopClosing).  A faulted or drained stream ends the wait: returns
+// NMI_ERR_NOT_READY when the stream is idle and the word still does not match.
+int wait_word(nmi_ctx *ctx, const volatile unsigned long long *word, unsigned long long mask, unsigned long long want,
+              unsigned long long *out)
+{
+    const uint64_t check_every = ctx->wait_mode == 1 ? 0x3F : 0xFFFF;
+    for (uint64_t spin = 0;; ++spin) {
+        const unsigned long long v = __atomic_load_n(word, __ATOMIC_ACQUIRE);
+        if ((v & mask) == want) {
+            *out = v;
+            return NMI_OK;
+        }
+        if (ctx->wait_mode == 1) sched_yield();
+        if ((spin & check_every) == check_every) {
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) {
+                const unsigned long long v2 = __atomic_load_n(word, __ATOMIC_ACQUIRE);
+                *out = v2;
+                return (v2 & mask) == want ? NMI_OK : NMI_ERR_NOT_READY;
+            }
+            if (q != hipErrorNotReady) return hip_fail(ctx, q, "hipStreamQuery");
+        }
+    }
+}
+
 // Blocks until the launch numbered ctx->seq has published its winner and returns it.
 int fetch_key(nmi_ctx *ctx, unsigned long long *key)
 {
     if (ctx->posted) {
         // The last workgroup stores (key | parity << 63) to fine-grained pinned memory; poll that one word.
-        const unsigned long long want = (unsigned long long)(ctx->seq & 1u);
-        for (uint64_t spin = 0;; ++spin) {
-            const unsigned long long word = __atomic_load_n(&ctx->mailbox->word, __ATOMIC_ACQUIRE);
-            if ((word >> 63) == want) {
-                *key = word & 0x7FFFFFFFFFFFFFFFull;
-                return NMI_OK;
-            }
-            if ((spin & 0xFFFF) == 0xFFFF) {
-                // a faulted or finished stream must not leave us spinning
-                const hipError_t q = hipStreamQuery(ctx->stream);
-                if (q == hipSuccess) break;  // stream drained: fall through to the copy path below
-                if (q != hipErrorNotReady) return hip_fail(ctx, q, "hipStreamQuery");
-            }
-        }
-        const unsigned long long word = __atomic_load_n(&ctx->mailbox->word, __ATOMIC_ACQUIRE);
-        if ((word >> 63) == want) {
+        unsigned long long word = 0;
+        const int rc = wait_word(ctx, &ctx->mailbox->word, 1ull << 63, (unsigned long long)(ctx->seq & 1u) << 63, &word);
+        if (rc == NMI_OK) {
             *key = word & 0x7FFFFFFFFFFFFFFFull;
             return NMI_OK;
         }
+        if (rc != NMI_ERR_NOT_READY) return rc;  // stream drained without a post: fall through to the copy path
     }
     NMI_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_key, ctx->d_keys + ctx->last_slot, sizeof(unsigned long long),
                                     hipMemcpyDeviceToHost, ctx->stream));
@@ -314,16 +386,17 @@ int nmi_create(const nmi_params *params, nmi_ctx **out_ctx)
         return fail(e, "hipHostMalloc(mailbox)");
     memset(ctx->mailbox, 0, sizeof(nmi::Mailbox));
     if ((e = hipMalloc((void **)&ctx->d_pair_rating, sizeof(float))) != hipSuccess) return fail(e, "hipMalloc(rating)");
+    if ((e = hipMalloc((void **)&ctx->d_reduced_key, sizeof(unsigned long long))) != hipSuccess) return fail(e, "hipMalloc(reduced key)");
+    if ((e = hipHostMalloc((void **)&ctx->score_mailbox, 2 * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped)) !=
+        hipSuccess)
+        return fail(e, "hipHostMalloc(score mailbox)");
+    memset(ctx->score_mailbox, 0, 2 * sizeof(unsigned long long));
     if ((e = hipHostMalloc((void **)&ctx->h_key, sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
         return fail(e, "hipHostMalloc(key)");
     if ((e = hipEventCreate(&ctx->ev_start)) != hipSuccess) return fail(e, "hipEventCreate");
     if ((e = hipEventCreate(&ctx->ev_stop)) != hipSuccess) return fail(e, "hipEventCreate");
     if ((e = nmi::launch_table(ctx->table, ctx->npix, ctx->stream)) != hipSuccess) return fail(e, "launch_table");
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");
-    if (p.max_candidates > 0 && (rc = ensure_ratings(ctx, p.max_candidates)) != NMI_OK) {
-        nmi_destroy(ctx);
-        return rc;
-    }
     *out_ctx = ctx;
     return NMI_OK;
 }
@@ -334,7 +407,9 @@ int nmi_destroy(nmi_ctx *ctx)
     DeviceGuard guard(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     if (ctx->table) (void)hipFree(ctx->table);
-    if (ctx->ratings) (void)hipFree(ctx->ratings);
+    if (ctx->d_reduced_key) (void)hipFree(ctx->d_reduced_key);
+    if (ctx->score_mailbox) (void)hipHostFree(ctx->score_mailbox);
+    if (ctx->d_slabs) (void)hipFree(ctx->d_slabs);
     if (ctx->d_keys) (void)hipFree(ctx->d_keys);
     if (ctx->d_done) (void)hipFree(ctx->d_done);
     if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
@@ -348,8 +423,10 @@ int nmi_destroy(nmi_ctx *ctx)
         if (ctx->mvp_ring.h[i]) (void)hipHostFree(ctx->mvp_ring.h[i]);
         if (ctx->mvp_ring.ev[i]) (void)hipEventDestroy(ctx->mvp_ring.ev[i]);
     }
-    if (ctx->d_order) (void)hipFree(ctx->d_order);
-    if (ctx->h_order) (void)hipHostFree(ctx->h_order);
+    for (auto &oe : ctx->orders) {
+        if (oe.d) (void)hipFree(oe.d);
+        if (oe.h) (void)hipHostFree(oe.h);
+    }
     for (int i = 0; i < nmi_ctx::kWarpRing; ++i) {
         if (ctx->d_warp_coeffs[i]) (void)hipFree(ctx->d_warp_coeffs[i]);
         if (ctx->h_warp_coeffs[i]) (void)hipHostFree(ctx->h_warp_coeffs[i]);
@@ -384,7 +461,16 @@ int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value)
     switch (option) {
     case NMI_OPT_HIST_VARIANT:
         if (value < 0 || value > 4) return NMI_ERR_INVALID_ARGUMENT;
+        if (value != 1 && value != 3 && !nmi::ablation_variants_built()) return NMI_ERR_UNSUPPORTED;  // -DNMI_BUILD_ABLATIONS
         ctx->hist_variant = (int)value;
+        return NMI_OK;
+    case NMI_OPT_SPLIT:
+        if (value != -1 && value != 0 && value != 2 && value != 4 && value != 8) return NMI_ERR_INVALID_ARGUMENT;
+        ctx->split_mode = (int)value;
+        return NMI_OK;
+    case NMI_OPT_WAIT_MODE:
+        if (value < 0 || value > 1) return NMI_ERR_INVALID_ARGUMENT;
+        ctx->wait_mode = (int)value;
         return NMI_OK;
     case NMI_OPT_PHASE_MASK:
         if (value < 0 || value > 31) return NMI_ERR_INVALID_ARGUMENT;
@@ -433,8 +519,17 @@ int nmi_get_info(nmi_ctx *ctx, int32_t *compute_units, int32_t *workgroups_per_l
 {
     if (!ctx) return NMI_ERR_INVALID_ARGUMENT;
     if (compute_units) *compute_units = ctx->compute_units;
-    if (workgroups_per_launch) *workgroups_per_launch = ctx->compute_units;
+    if (workgroups_per_launch) *workgroups_per_launch = ctx->workgroups > 0 ? ctx->workgroups : ctx->compute_units;
     if (lds_bytes) *lds_bytes = nmi::grid_kernel_lds_bytes();
+    return NMI_OK;
+}
+
+int nmi_copy_term_table(nmi_ctx *ctx, float *h_out, int64_t n)
+{
+    if (!ctx || !h_out || n != (int64_t)ctx->npix + 1) return NMI_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(ctx->device);
+    NMI_HIP_TRY(ctx, hipMemcpyAsync(h_out, ctx->table, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return NMI_OK;
 }
 
@@ -483,6 +578,9 @@ int nmi_search_grid_block(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S_l
         rc = fetch_key(ctx, &k);
         if (rc != NMI_OK) return rc;
         *h_key = k;
+        // The winner is posted by the last workgroup before the kernel has retired: a caller that asked for the rating
+        // table may read it right after this call, from any stream, so the table must be complete (and written back).
+        if (d_ratings || d_key) NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     return NMI_OK;
 }
@@ -502,10 +600,23 @@ int nmi_eval_pair_debug(nmi_ctx *ctx, const uint8_t *render, const uint8_t *warp
     if (!ctx || !render || !warped || !h_score) return NMI_ERR_INVALID_ARGUMENT;
     ctx->detail.clear();
     DeviceGuard guard(ctx->device);
+    const bool dbg = d_joint || d_hist_render || d_hist_warped || d_sums;
     int rc = enqueue_grid(ctx, render, 1, 0, 1, warped, 1, ctx->d_pair_rating, nullptr, false, d_joint, d_hist_render,
-                          d_hist_warped, d_sums);
+                          d_hist_warped, d_sums, 0, /*post_score=*/true);
     if (rc != NMI_OK) return rc;
-    // kernel.cu:100: the blocking 4-byte copy of the score back to the caller.
+    if (ctx->result_path == 1) {
+        // kernel.cu:100 copies the score back with a blocking cudaMemcpy; here the scoring lane stores
+        // (score bits | call number << 32) into pinned host memory and the call polls that word (~10 us less per call).
+        unsigned long long word = 0;
+        rc = wait_word(ctx, ctx->score_mailbox, 0xFFFFFFFF00000000ull, (unsigned long long)ctx->pair_seq << 32, &word);
+        if (rc == NMI_OK) {
+            const uint32_t bits = (uint32_t)word;
+            memcpy(h_score, &bits, sizeof bits);
+            if (dbg) NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the exported histograms must be complete
+            return NMI_OK;
+        }
+        if (rc != NMI_ERR_NOT_READY) return rc;
+    }
     NMI_HIP_TRY(ctx, hipMemcpyAsync(h_score, ctx->d_pair_rating, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return NMI_OK;

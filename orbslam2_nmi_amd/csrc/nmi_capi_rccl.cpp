@@ -95,22 +95,33 @@ int nmi_rccl_comm_destroy(void *nccl_comm)
     return r == 0 ? NMI_OK : NMI_ERR_RCCL - r;
 }
 
+int nmi_search_grid_block_rccl(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S_local, int32_t s_offset, int32_t S_total,
+                               const uint8_t *warp_stack, int32_t Wn_local, int32_t w_offset, int32_t Wn_total, float *d_ratings,
+                               void *nccl_comm, int64_t *h_best_index, float *h_best_score)
+{
+    if (!nccl_comm) return NMI_ERR_INVALID_ARGUMENT;
+    if (!rccl().ok) return NMI_ERR_UNSUPPORTED;
+    int rc = nmi_search_grid_block(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn_local, w_offset, Wn_total, d_ratings,
+                                   nullptr, nullptr);
+    if (rc != NMI_OK) return rc;
+    DeviceGuard guard(ctx->device);
+    // The only exchange of the search: 8 bytes per rank, max over ranks.  Out of place: the send
+    // buffer is this launch's key slot (zero for a rank whose block is empty), the receive buffer a word of its own, so
+    // the global winner never lands in a ping-pong slot that a later launch expects to find zero.
+    const unsigned long long *send = ctx->d_keys + ctx->last_slot;
+    int r = rccl().all_reduce(send, ctx->d_reduced_key, 1, kNcclUint64, kNcclMax, nccl_comm, ctx->stream);
+    if (r != 0) return rccl_fail(ctx, r, "ncclAllReduce");
+    NMI_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_key, ctx->d_reduced_key, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return nmi_key_unpack(*ctx->h_key, h_best_index, h_best_score);
+}
+
 int nmi_search_grid_rccl(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S_local, int32_t s_offset, int32_t S_total,
                          const uint8_t *warp_stack, int32_t Wn, float *d_ratings, void *nccl_comm, int64_t *h_best_index,
                          float *h_best_score)
 {
-    if (!nccl_comm) return NMI_ERR_INVALID_ARGUMENT;
-    if (!rccl().ok) return NMI_ERR_UNSUPPORTED;
-    int rc = nmi_search_grid_shard(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn, d_ratings, nullptr, nullptr);
-    if (rc != NMI_OK) return rc;
-    DeviceGuard guard(ctx->device);
-    // The only exchange of the search: 8 bytes per rank, max over ranks.
-    unsigned long long *k = ctx->d_keys + ctx->last_slot;
-    int r = rccl().all_reduce(k, k, 1, kNcclUint64, kNcclMax, nccl_comm, ctx->stream);
-    if (r != 0) return rccl_fail(ctx, r, "ncclAllReduce");
-    NMI_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_key, k, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return nmi_key_unpack(*ctx->h_key, h_best_index, h_best_score);
+    return nmi_search_grid_block_rccl(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn, 0, Wn, d_ratings, nccl_comm,
+                                      h_best_index, h_best_score);
 }
 
 }  // extern "C"

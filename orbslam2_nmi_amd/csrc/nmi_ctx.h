@@ -34,8 +34,6 @@ struct nmi_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     float *table = nullptr;             // [npix + 1]
-    float *ratings = nullptr;           // internal rating table
-    int64_t ratings_cap = 0;
     unsigned long long *d_keys = nullptr;  // two device slots for the packed winner, used alternately (ping-pong)
     unsigned long long *h_key = nullptr;   // pinned host mirror (copy path)
     unsigned int *d_done = nullptr;        // finished-workgroup counter
@@ -43,14 +41,29 @@ struct nmi_ctx {
     unsigned int seq = 0;                  // launches that post to the mailbox so far (blocking calls only)
     int slot = 0;                          // key slot of the next launch
     int last_slot = 0;                     // key slot of the most recent launch
+    int last_parts = 0;                    // parts per candidate of the most recent launch (0 = one workgroup per candidate)
     int result_path = 1;                   // 1 mailbox spin (default), 0 hipMemcpyAsync + stream sync
     bool posted = false;                   // the most recent launch posts to the mailbox
     float *d_pair_rating = nullptr;
-    int *d_order = nullptr;               // visiting order of the candidates (XCD-aware tiling), cached per grid shape
-    int *h_order = nullptr;
-    int64_t order_cap = 0;
-    int order_S = -1, order_Wn = -1;
+    unsigned long long *d_reduced_key = nullptr;  // receive buffer of the RCCL all-reduce (never one of the ping-pong slots)
+    unsigned long long *score_mailbox = nullptr;  // pinned, fine-grained: nmi_eval_pair's (score bits | sequence << 32)
+    unsigned int pair_seq = 0;                    // nmi_eval_pair calls that posted so far
+    int wait_mode = 0;                            // NMI_OPT_WAIT_MODE: 0 spin on the mailbox, 1 yield the core between polls
+    // Visiting orders of the candidates (XCD-aware tiling), one per grid shape seen, so that a coarse-to-fine search
+    // alternating between shapes (translation level 27 x 1, rotation level 1 x 27, ...) never waits for the stream.
+    struct OrderEntry {
+        int S = -1, Wn = -1;
+        int *d = nullptr, *h = nullptr;
+        int64_t cap = 0;
+        uint64_t last_use = 0;
+    };
+    static constexpr int kOrderCache = 16;
+    OrderEntry orders[kOrderCache];
+    uint64_t order_clock = 0;
     int xcd_tiling = 1;                   // NMI_OPT_XCD_TILING
+    nmi::SplitSlab *d_slabs = nullptr;    // hand-off slabs of the split kernel, one per candidate
+    int slab_cap = 0;
+    int split_mode = -1;                  // NMI_OPT_SPLIT: -1 automatic, 0 never, 2 / 4 / 8 parts whenever the grid fits
     uint32_t *d_zbuf = nullptr;           // depth|colour anchor buffers of the point-cloud renderer (padded, per view)
     int64_t zbuf_cap = 0;
     void *d_tile_queue = nullptr;          // mesh renderer: (triangle, view, tile) work items of large triangles
@@ -91,12 +104,13 @@ namespace nmi_internal {
 int ensure_tile_queue(nmi_ctx *ctx);
 
 int hip_fail(nmi_ctx *ctx, hipError_t e, const char *what);
-int ensure_ratings(nmi_ctx *ctx, int64_t n);
 void build_order(int S, int Wn, int *order);
-int ensure_order(nmi_ctx *ctx, int S, int Wn);
+int ensure_order(nmi_ctx *ctx, int S, int Wn, const int **d_order);
 int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_offset, int S_total, const uint8_t *warp_stack, int Wn,
                  float *d_ratings, unsigned long long *out_key, bool post, uint32_t *dbg_joint, uint32_t *dbg_h1, uint32_t *dbg_h2,
-                 float *dbg_sums, int w_offset = 0);
+                 float *dbg_sums, int w_offset = 0, bool post_score = false);
+int wait_word(nmi_ctx *ctx, const volatile unsigned long long *word, unsigned long long mask, unsigned long long want,
+              unsigned long long *out);
 int stage_floats(nmi_ctx *ctx, StagingRing &ring, const float *h_src, size_t n, float **d_out);
 int fetch_key(nmi_ctx *ctx, unsigned long long *key);
 int check_grid_args(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_offset, int S_total, const uint8_t *warp_stack,

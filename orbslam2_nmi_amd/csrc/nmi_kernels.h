@@ -42,6 +42,8 @@ struct GridArgs {
     unsigned int *done;             // count of finished workgroups (zero on entry, left zero)
     Mailbox *mailbox;               // pinned host memory the last workgroup posts the winner to, or nullptr
     unsigned int seq;               // sequence number of this posting launch (its parity is posted with the winner)
+    unsigned long long *score_post; // nmi_eval_pair: pinned host word that receives (score bits | seq << 32), or nullptr
+    struct SplitSlab *slabs;        // split kernel: one hand-off slab per candidate (see nmi_split_kernel.hip)
     uint32_t *dbg_joint, *dbg_h1, *dbg_h2;
     float *dbg_sums;
     int hist_variant;             // 0 per-pixel wrap test, 1 batched, 2 unchecked (ablation), 3 optimistic + verify (default), 4 pipelined (experimental)
@@ -64,6 +66,19 @@ inline void set_geometry(GridArgs &a, int width, int height, const void *render_
 
 hipError_t launch_table(float *table, int npix, hipStream_t stream);
 hipError_t launch_grid(const GridArgs &a, int workgroups, bool use_bg, hipStream_t stream);
+bool ablation_variants_built();  // HIST variants 0 / 2 / 4 compiled in (-DNMI_BUILD_ABLATIONS)?
+
+// Split form for grids with fewer candidates than compute units (nmi_split_kernel.hip): K workgroups per candidate, each
+// owning 256 / K complete rows (render intensities) of the joint histogram as 32-bit LDS counters.  parts = 2, 4 or 8.
+struct SplitSlab {
+    float row_sums[256];        // joint-row entropy sums (d_JointEntropyShort, kernel.cu:60,90), each row by its owner
+    uint32_t hist_render[256];  // render marginal = row sums of the counts, each row by its owner
+    uint32_t hw_part[8][256];   // frame marginal: column sums over the rows of each part
+    uint32_t ticket;            // arrivals; the last part to arrive scores the candidate and resets it
+    uint32_t pad[63];
+};
+hipError_t launch_split(const GridArgs &a, int parts, int workgroups, bool use_bg, hipStream_t stream);
+int split_workgroups(int candidates, int parts);  // grid size that keeps the parts of a candidate on one XCD
 int grid_kernel_lds_bytes();
 size_t grid_kernel_scratch_bytes(int workgroups);
 hipError_t launch_warp(const uint8_t *frame, const float *coeffs /*[Wn][9] inverse maps*/, uint8_t *out, int width,

@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "nmi_kernels.h"
+#include "nmi_device.h"
 
 namespace nmi {
 
@@ -60,49 +61,6 @@ struct Lds {
 __device__ __forceinline__ int slot_in_round(int b, int grid) { return (grid & 7) == 0 ? (b & 7) * (grid >> 3) + (b >> 3) : b; }
 __device__ __forceinline__ int candidate_at(const GridArgs &a, int ordinal) { return a.order ? a.order[ordinal] : ordinal; }
 
-// ---- cross-lane helpers (DPP within a row of 16 lanes: lane i receives lane i + N) -------------------
-template <int N>
-__device__ __forceinline__ float row_shl(float x)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x100 + N, 0xF, 0xF, true));
-}
-template <int N>
-__device__ __forceinline__ uint32_t row_shl(uint32_t x)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x100 + N, 0xF, 0xF, true);
-}
-// Tree steps n = 8,4,2,1 over one value per lane of a 16-lane row: lane t < n takes a[t] += a[t + n];
-// the sum ends in lane 0 of the row.
-__device__ __forceinline__ float row_tree_16(float x)
-{
-    x = x + row_shl<8>(x);
-    x = x + row_shl<4>(x);
-    x = x + row_shl<2>(x);
-    x = x + row_shl<1>(x);
-    return x;
-}
-__device__ __forceinline__ uint32_t row_sum_16(uint32_t x)
-{
-    x += row_shl<8>(x);
-    x += row_shl<4>(x);
-    x += row_shl<2>(x);
-    x += row_shl<1>(x);
-    return x;
-}
-// In-lane part of the 256-element stride-halving tree for a lane that owns elements
-// t = i + 16*j (j = 0..15, any rotation of j): steps n = 128, 64, 32, 16 pair j with j + n/16.
-__device__ __forceinline__ float lane_tree_16(const float (&lo)[8], const float (&hi)[8])
-{
-    float s[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s[k] = lo[k] + hi[k];  // n = 128
-#pragma unroll
-    for (int k = 0; k < 4; ++k) s[k] = s[k] + s[k + 4];  // n = 64
-    s[0] = s[0] + s[2];                                  // n = 32
-    s[1] = s[1] + s[3];
-    return s[0] + s[1];                                  // n = 16
-}
-
 // ---- histogram phase -------------------------------------------------------------------------------
 // One pixel -> one LDS atomic on the packed joint histogram (the reference does three atomics per
 // pixel, NMI.cu:46-48; the marginals are recovered as row / column sums of the joint).
@@ -136,19 +94,6 @@ __device__ __forceinline__ void add_pixel(Lds &lds, int par, uint32_t d1, uint32
     const uint32_t old = __hip_atomic_fetch_add(&lds.joint[word], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const uint32_t field = val * 0xFFFFu;
     if (__builtin_expect((old & field) == field, 0)) record_wrap(lds, par, word, val, old);
-}
-
-// Cheap necessary condition for a flat chunk, wavefront-uniform: first dword == last dword in both images for every
-// active lane (2 VALU compares + scalar work); the full test runs only where this holds.
-__device__ __forceinline__ bool flat_hint(const uint4 &rv, const uint4 &wv)
-{
-    // spelled out: from "__all(...)" hipcc builds compare, select 0/1, compare again, two scalar tests
-    unsigned long long m;
-    asm volatile("v_cmp_eq_u32 vcc, %1, %2\n\tv_cmp_eq_u32 %0, %3, %4\n\ts_and_b64 %0, %0, vcc"
-                 : "=s"(m)
-                 : "v"(rv.x), "v"(rv.w), "v"(wv.x), "v"(wv.w)
-                 : "vcc");
-    return m == __builtin_amdgcn_read_exec();
 }
 
 // Flat chunks.  When, for every active lane of the wavefront, all 16 pixels of the lane carry the same (render, frame)
@@ -568,36 +513,7 @@ __device__ __forceinline__ void final_phase(Lds &lds, const GridArgs &a, int lan
             if (a.dbg_h2) a.dbg_h2[t] = lds.hist_warped[t];
         }
     }
-    if (lane == 0) {
-        // NMI.cu:342-362, evaluated from the three completed sums (the reference reads them across
-        // blocks without synchronisation, NMI.cu:340-342).
-        float score;
-        if (a1 == 0.0f && a2 == 0.0f && a3 == 0.0f)
-            score = 0.0f;
-        else if (a.mode == NMI_MODE_ENMI_)
-            score = ((-a1) + (-a2)) / (-a3);
-        else if (a.mode == NMI_MODE_SUC_)
-            score = 2.0f * (1.0f - ((-a3) / ((-a1) + (-a2))));
-        else
-            score = -1.0f;
-        if (a.ratings) a.ratings[p] = score;
-        if (a.dbg_sums) {
-            a.dbg_sums[0] = a1;
-            a.dbg_sums[1] = a2;
-            a.dbg_sums[2] = a3;
-        }
-        // find_max_elements, helperFunctions.cpp:52-101: max starts at 0, strict '>', first cell equal to
-        // the max wins.  Non-negative floats order like their bit patterns, so one 64-bit max of
-        // (score bits, inverted global index) reproduces it; negative / NaN scores contribute nothing.
-        if (score >= 0.0f) {
-            const uint32_t bits = score == 0.0f ? 0u : __float_as_uint(score);
-            const uint32_t gidx = (uint32_t)(a.w_offset + w) * (uint32_t)a.S_total + (uint32_t)(a.s_offset + s);
-            const unsigned long long key = ((unsigned long long)bits << 32) | (unsigned long long)(0xFFFFFFFFu - gidx);
-            // returning form: the value is not needed, but its arrival (awaited once, at kernel end) proves the
-            // max was performed, which the completion protocol below builds on
-            prev_key = __hip_atomic_fetch_max(a.key, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    if (lane == 0) commit_score(a, p, w, s, a1, a2, a3, prev_key);
 }
 
 // One candidate start to finish on the exact path (returning atomics + wrap bookkeeping + flat-region folding), all 16
@@ -622,27 +538,6 @@ __device__ __forceinline__ void exact_candidate(Lds &lds, const GridArgs &a, int
         if (lane < kSide) lds.side_key[0][lane] = lds.side_cnt[0][lane] = 0;
     }
     __syncthreads();
-}
-
-// Completion, called by lane 0 of each workgroup when it has scored its last candidate: the last workgroup to finish
-// publishes the winner.  Every atomicMax of final_phase and the counter below are device-scope read-modify-writes
-// performed at the memory side.  The counter increment carries a data dependency on the values returned by this
-// workgroup's maxes, so it is issued after they were performed; the workgroup that draws the last ticket therefore
-// reads the final key.  Nothing here needs a cache write-back: the key travels in atomics, and the mailbox is one
-// 8-byte store (key in bits 0..62, launch parity in bit 63 -- scores are non-negative floats, bit 63 is free).
-__device__ __forceinline__ void publish_winner(const GridArgs &a, unsigned long long prev_key)
-{
-    const unsigned int one = prev_key == ~0ull ? 2u : 1u;  // always 1 (a key never has all bits set)
-    const unsigned int arrived = __hip_atomic_fetch_add(a.done, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (arrived == gridDim.x - 1) {
-        const unsigned long long final_key = __hip_atomic_load(a.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (a.out_key)  // may be pinned host memory that a caller polls (nmi_level_run)
-            __hip_atomic_store(a.out_key, final_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (a.mailbox)
-            __hip_atomic_store(&a.mailbox->word, final_key | ((unsigned long long)(a.seq & 1u) << 63), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
-    }
 }
 
 }  // namespace
@@ -748,6 +643,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
     if (tid == 0 && !(a.phase_mask & 16)) publish_winner(a, prev_key);  // bit 4: timing experiment without the protocol (no result)
 }
 
+#ifdef NMI_BUILD_ABLATIONS  // experiments kept for tools/ablate.py; not part of the shipped library
 // ---------------------------------------------------------------------------------------------------------
 // Pipelined ("wavefront-specialised") form of the same computation (NMI_OPT_HIST_VARIANT = 4, experimental).
 // Exact, covered by the parity tests, but measured SLOWER than the sequential kernel on MI355X (114 vs 95 us per 729
@@ -960,6 +856,8 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel_ws(GridArgs
     if (tid == 0) publish_winner(a, prev_key);
 }
 
+#endif  // NMI_BUILD_ABLATIONS
+
 // table[c] = (c/len) * log2(c/len) in the reference's fp32 form (NMI.cu:245): p = fl32(c/len),
 // l = log2 of p rounded once to fp32 (evaluated in fp64 so the rounding is the correct one; CUDA's
 // and glibc's log2f are each within 1 ulp of it), term = fl32(p * l).
@@ -1005,9 +903,7 @@ hipError_t launch_grid(const GridArgs &a, int workgroups, bool use_bg, hipStream
 {
     dim3 grid(workgroups), block(kBlock);
     switch (a.hist_variant) {
-    case 0: launch_hist<0>(a, grid, block, use_bg, stream); break;
     case 1: launch_hist<1>(a, grid, block, use_bg, stream); break;
-    case 2: launch_hist<2>(a, grid, block, use_bg, stream); break;
     case 3:
         // The wrap detector of HIST = 3 needs the expected pixel count, which is W*H only with BG on.
         if (use_bg)
@@ -1015,8 +911,11 @@ hipError_t launch_grid(const GridArgs &a, int workgroups, bool use_bg, hipStream
         else
             launch_hist<1>(a, grid, block, use_bg, stream);
         break;
-    default:
-        // 4 = pipelined kernel (experimental).  It has no debug exports and needs BG on.
+#ifdef NMI_BUILD_ABLATIONS
+    case 0: launch_hist<0>(a, grid, block, use_bg, stream); break;
+    case 2: launch_hist<2>(a, grid, block, use_bg, stream); break;
+    case 4:
+        // pipelined kernel (experimental).  It has no debug exports and needs BG on.
         if (use_bg && !a.dbg_joint && !a.dbg_h1 && !a.dbg_h2 && !a.dbg_sums) {
             if (a.shift != 0)
                 hipLaunchKernelGGL((nmi_grid_kernel_ws<true>), grid, block, 0, stream, a);
@@ -1028,8 +927,19 @@ hipError_t launch_grid(const GridArgs &a, int workgroups, bool use_bg, hipStream
             launch_hist<1>(a, grid, block, use_bg, stream);
         }
         break;
+#endif
+    default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+bool ablation_variants_built()
+{
+#ifdef NMI_BUILD_ABLATIONS
+    return true;
+#else
+    return false;
+#endif
 }
 
 int grid_kernel_lds_bytes() { return (int)sizeof(Lds); }

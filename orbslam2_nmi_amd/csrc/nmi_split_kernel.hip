@@ -1,0 +1,418 @@
+// nmi_split_kernel.hip -- the scoring path for grids with fewer candidates than compute units: K workgroups per candidate.
+//
+// Why: nmi_grid_kernel gives a candidate to ONE workgroup on one of the 256 CUs.  The reference's own call site evaluates
+// one candidate per call (CUDAF::NMIWithCuda_noMask, Thirdparty/CUDA_Functions/kernel.cu:49-114, called from the loop at
+// src/Tracking.cc:1879-1902), and the search strategy routinely collapses axes to a single cell (Tracking.cc:2014-2043,
+// nmiSearchKernel.cpp:124-141): grids of 1, 3, 9, 27, 81 candidates are the common case, and they leave most of the chip idle.
+//
+// How: the K workgroups of a candidate split the joint histogram by RENDER INTENSITY (its rows): part j owns rows
+// [j * 256/K, (j+1) * 256/K) as 32-bit LDS counters (K = 8: 32 KiB).  Every part streams ALL pixels of the pair (0.6 MB,
+// from the XCD's L2 after the first part touched them: the parts of a candidate are placed on one XCD) but issues the
+// LDS atomic only for pixels whose render intensity falls into its rows.  Each part therefore holds COMPLETE rows:
+//   * no merge of partial histograms (what sank the pixel-split attempt of round 1: device-scope atomics);
+//   * 32-bit counters: no wrap bookkeeping, BG-off and reduced-bin contexts take the same path;
+//   * the row trees of AddvectorParwiseMidKernel (NMI.cu:270-287) run per row exactly as in nmi_grid_kernel, so the
+//     256 row sums and the render marginal are final when a part stores them.
+// What crosses workgroups is small: 256/K row sums + 256/K render-marginal counts + 256 partial column sums per part
+// (2.3 KB at K = 8), written to a per-candidate slab with sc1 (L2-bypassing) stores.  A device-scope ticket tells the
+// part that arrives last; it reads the slab with sc1 loads, sums the K column partials (integers: order-free), runs the
+// three 256-element trees of AddVectorPairwiseKernel (NMI.cu:290-339) in the reference's order and forms the score.
+// Results are bit-identical to nmi_grid_kernel's (tests/test_gpu_parity.py runs every grid test through both).
+// Hand-off form: MI355X_MICROARCH.md "inter-workgroup visibility", table row 1 (sc1 stores -> every wave s_waitcnt
+// vmcnt(0) -> workgroup barrier -> one agent-scope atomic add; the adder that came last loads after its add returned,
+// the other waves after a barrier).  One workgroup per CU (LDS padded) as that row requires.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nmi_device.h"
+#include "nmi_kernels.h"
+
+namespace nmi {
+
+namespace {
+
+constexpr int kBlock = NMI_BLOCK_THREADS;
+constexpr int kWaves = kBlock / 64;
+constexpr int kBins = 256;
+constexpr int kMinLdsBytes = 84 * 1024;  // more than half of the CU's 160 KiB: one workgroup per CU
+
+template <int K>
+struct SplitLds {
+    static constexpr int kRows = kBins / K;
+    static constexpr int kUsed = (kRows * kBins + kBins + 4) * 4;
+    uint32_t joint[kRows * kBins];  // [row = render intensity - part * kRows][frame intensity]; bank = frame intensity & 31
+    uint32_t hist_warped[kBins];    // column sums over this part's rows
+    uint32_t is_last;
+    uint32_t pad0[3];
+    uint32_t pad[kUsed < kMinLdsBytes ? (kMinLdsBytes - kUsed) / 4 : 4];
+};
+
+template <typename T>
+__device__ __forceinline__ void store_sc1(T *p, T v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t load_sc1(const uint32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float load_sc1(const float *p)
+{
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// 16 pixels of one lane, hot case (BG on, 256 bins).  xorpat holds (part * kRows) in every byte: after r ^= xorpat a pixel
+// belongs to this part iff its render byte is < kRows, and that byte is its local row.  One v_perm_b32 then builds the
+// 16-bit counter indices (row << 8 | frame intensity) of TWO pixels; index * 4 is the LDS byte address, and "address
+// inside the joint array" is the ownership test: per pixel 1/4 xor + 1/2 perm + 1 shift (SDWA word select) + 1 compare.
+template <int K>
+__device__ __forceinline__ void add_chunk_split(uint32_t *joint, const uint4 &rv, const uint4 &wv, uint32_t xorpat)
+{
+    constexpr uint32_t kLimit = (uint32_t)(kBins / K) * kBins * 4u;
+    char *const base = reinterpret_cast<char *>(joint);
+    const uint32_t r[4] = {rv.x ^ xorpat, rv.y ^ xorpat, rv.z ^ xorpat, rv.w ^ xorpat};
+    const uint32_t w[4] = {wv.x, wv.y, wv.z, wv.w};
+    const uint32_t two = 2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        // v_perm_b32: selector bytes 0-3 pick from the second operand (frame), 4-7 from the first (render)
+        const uint32_t k01 = __builtin_amdgcn_perm(r[q], w[q], 0x05010400u);  // (r0 << 8 | w0) | (r1 << 8 | w1) << 16
+        const uint32_t k23 = __builtin_amdgcn_perm(r[q], w[q], 0x07030602u);
+        uint32_t a0, a1, a2, a3;
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(a0) : "v"(two), "v"(k01));
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(a1) : "v"(two), "v"(k01));
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(a2) : "v"(two), "v"(k23));
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(a3) : "v"(two), "v"(k23));
+        if (__builtin_expect(a0 < kLimit, 1)) (void)__hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(base + a0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__builtin_expect(a1 < kLimit, 1)) (void)__hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(base + a1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__builtin_expect(a2 < kLimit, 1)) (void)__hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(base + a2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__builtin_expect(a3 < kLimit, 1)) (void)__hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(base + a3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+// One pixel, any switch setting (NMI.cu:85 background rule on the raw intensities, then intensity >> shift).
+template <int K>
+__device__ __forceinline__ void add_pixel_split(uint32_t *joint, uint32_t d1, uint32_t d2, int part, bool use_bg, int shift, uint32_t weight = 1)
+{
+    constexpr uint32_t kRows = kBins / K;
+    if (!use_bg && (d1 == 0 || d2 == 0)) return;
+    d1 >>= shift;
+    d2 >>= shift;
+    if (d1 / kRows != (uint32_t)part) return;
+    (void)__hip_atomic_fetch_add(&joint[(d1 % kRows) * kBins + d2], weight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// A chunk in the careful loop of the hot path: folded when every active lane's 16 pixels carry one (render, frame) pair
+// (see fold_flat_chunk in nmi_kernels.hip for why: 64 lanes adding to one LDS address serialise), added plainly otherwise.
+template <int K>
+__device__ __forceinline__ void add_chunk_careful(uint32_t *joint, const uint4 &rv, const uint4 &wv, uint32_t xorpat, int part)
+{
+    const uint32_t rb = rv.x & 0xFFu, wb = wv.x & 0xFFu;
+    const bool flat = rv.x == rv.y && rv.y == rv.z && rv.z == rv.w && wv.x == wv.y && wv.y == wv.z && wv.z == wv.w &&
+                      rv.x == rb * 0x01010101u && wv.x == wb * 0x01010101u;
+    if (!__all(flat)) {
+        add_chunk_split<K>(joint, rv, wv, xorpat);
+        return;
+    }
+    const uint32_t key = (rb << 8) | wb;
+    const uint32_t key0 = __builtin_amdgcn_readfirstlane(key);
+    uint32_t weight = 16;
+    bool issue = true;
+    if (__all(key == key0)) {  // one lane speaks for the wavefront
+        const unsigned long long active = __ballot(1);
+        weight = 16u * (uint32_t)__popcll(active);
+        issue = __lane_id() == (uint32_t)__ffsll((long long)active) - 1u;
+    }
+    if (issue) add_pixel_split<K>(joint, rb, wb, part, true, 0, weight);
+}
+
+// Histogram phase of one part: histogram256Kernel's pixel loop (NMI.cu:79-87) over ALL pixels of the pair, counting
+// only the pixels whose render intensity belongs to this part's rows.
+template <int K, bool FAST>
+__device__ __forceinline__ void histogram_split(uint32_t *joint, const GridArgs &a, const uint8_t *__restrict__ render,
+                                                const uint8_t *__restrict__ warped, int tid, int part, bool use_bg)
+{
+    constexpr int NT = kBlock;
+    constexpr uint32_t kRows = kBins / K;
+    if (a.vec_ok) {
+        const int nchunks = a.npix >> 4;
+        const int last = nchunks - 1;
+        auto ldw = [&](int c) { return *reinterpret_cast<const uint4 *>(warped + ((uint32_t)min(c, last) << 4)); };
+        // NMI.cu:82: row y of the frame meets row H-1-y of a bottom-up render (see histogram_phase in nmi_kernels.hip)
+        auto ldr = [&](int c) {
+            c = min(c, last);
+            const int y = (int)__umulhi((uint32_t)c, a.cpr_magic);
+            return *reinterpret_cast<const uint4 *>(render + ((uint32_t)(__mul24(y, a.flip_row) + c + a.flip_base) << 4));
+        };
+        if (FAST) {
+            // Four named register sets: three chunk pairs (96 B per lane, 96 KiB per workgroup) are in flight while one is
+            // added -- a part has to pull the whole pair through one CU in a few microseconds.  Loads are unconditional
+            // (index clamped), only the adds are predicated.  A flat hint (first dword == last dword in both images for the
+            // whole wavefront) sends the wavefront to the careful loop for the rest of the candidate.
+            const uint32_t xorpat = (uint32_t)part * kRows * 0x01010101u;
+            const int iters = (nchunks + NT - 1) / NT;
+            int resume = -1;
+            int ch = tid;
+            uint4 w0 = ldw(ch), r0 = ldr(ch), w1 = ldw(ch + NT), r1 = ldr(ch + NT), w2 = ldw(ch + 2 * NT), r2 = ldr(ch + 2 * NT), w3, r3;
+            const bool fold = !(a.phase_mask & 4);
+#define NMI_SPLIT_STEP(RC, WC, OFF)                                          \
+    if (fold && __builtin_expect(flat_hint(RC, WC), 0)) {                    \
+        resume = ch + (OFF) * NT;                                            \
+        break;                                                               \
+    }                                                                        \
+    if (ch + (OFF) * NT < nchunks) add_chunk_split<K>(joint, RC, WC, xorpat);
+            for (int it = 0; it < iters; it += 4) {
+                w3 = ldw(ch + 3 * NT);
+                r3 = ldr(ch + 3 * NT);
+                NMI_SPLIT_STEP(r0, w0, 0)
+                w0 = ldw(ch + 4 * NT);
+                r0 = ldr(ch + 4 * NT);
+                NMI_SPLIT_STEP(r1, w1, 1)
+                w1 = ldw(ch + 5 * NT);
+                r1 = ldr(ch + 5 * NT);
+                NMI_SPLIT_STEP(r2, w2, 2)
+                w2 = ldw(ch + 6 * NT);
+                r2 = ldr(ch + 6 * NT);
+                NMI_SPLIT_STEP(r3, w3, 3)
+                ch += 4 * NT;
+            }
+#undef NMI_SPLIT_STEP
+            if (resume >= 0) {
+                uint4 wc = ldw(resume), rc = ldr(resume);
+#pragma unroll 1
+                for (int c = resume; c < nchunks; c += NT) {
+                    const uint4 wn = ldw(c + NT), rn = ldr(c + NT);
+                    add_chunk_careful<K>(joint, rc, wc, xorpat, part);
+                    wc = wn;
+                    rc = rn;
+                }
+            }
+        } else {
+            // BG off and / or reduced bins: per-pixel form on 16-byte loads, one chunk of prefetch
+            uint4 wc = ldw(tid), rc = ldr(tid);
+#pragma unroll 1
+            for (int c = tid; c < nchunks; c += NT) {
+                const uint4 wn = ldw(c + NT), rn = ldr(c + NT);
+                const uint32_t r[4] = {rc.x, rc.y, rc.z, rc.w}, w[4] = {wc.x, wc.y, wc.z, wc.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        add_pixel_split<K>(joint, (r[q] >> (8 * j)) & 0xFFu, (w[q] >> (8 * j)) & 0xFFu, part, use_bg, a.shift);
+                wc = wn;
+                rc = rn;
+            }
+        }
+    } else {
+        // Any width / alignment: byte loads, position arithmetic as written in NMI.cu:79-83.
+        for (int pos = tid; pos < a.npix; pos += NT) {
+            const int y = pos / a.width;
+            const int x = pos - y * a.width;
+            const int ry = a.flip ? (a.height - 1 - y) : y;
+            add_pixel_split<K>(joint, render[ry * a.width + x], warped[pos], part, use_bg, a.shift);
+        }
+    }
+}
+
+// Decode of this part's rows: counters -> per-bin terms (ComputeEntropyKernel, NMI.cu:242-263, through the per-count
+// table) -> row trees (AddvectorParwiseMidKernel, NMI.cu:270-287).  Same lane / word ownership as decode_phase in
+// nmi_kernels.hip: a wavefront takes 4 rows per pass, one per 16-lane DPP row; lane i of a row owns the bins
+// d2 = i + 16*j, so the tree steps n = 128..16 are in-lane adds and n = 8..1 DPP shifts.  Odd DPP rows start one group
+// later so that the two rows of a 32-lane LDS access group hit disjoint banks.  Counters are cleared as they are read.
+template <int K>
+__device__ __forceinline__ void decode_split(SplitLds<K> &lds, const GridArgs &a, SplitSlab *slab, int part, int wave, int lane)
+{
+    constexpr int kRows = kBins / K;
+    const int i = lane & 15, r = lane >> 4, o = r & 1;
+    uint32_t col_lo[8], col_hi[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) col_lo[k] = col_hi[k] = 0;
+    bool any = false;
+#pragma unroll 1
+    for (int row0 = wave * 4; row0 < kRows; row0 += kWaves * 4) {
+        any = true;
+        const int row = row0 + r, d1 = part * kRows + row;
+        uint32_t *jr = lds.joint + row * kBins;
+        uint32_t lo[8], hi[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = i + 16 * ((k + o) & 7);
+            lo[k] = jr[q];
+            hi[k] = jr[q + 128];
+            jr[q] = 0;  // ready for the next candidate
+            jr[q + 128] = 0;
+        }
+        float tl[8], th[8];
+        uint32_t rsum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            col_lo[k] += lo[k];
+            col_hi[k] += hi[k];
+            rsum += lo[k] + hi[k];
+            tl[k] = a.table[lo[k]];  // table[0] = 0: no branch for empty bins (most of them; one cached line)
+            th[k] = a.table[hi[k]];
+        }
+        rsum = row_sum_16(rsum);
+        const float x = row_tree_16(lane_tree_16(tl, th));
+        if (i == 0) {
+            store_sc1(&slab->row_sums[d1], x);
+            store_sc1(&slab->hist_render[d1], rsum);
+        }
+        if (a.dbg_joint) {
+            uint32_t *out = a.dbg_joint + d1 * kBins;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int q = i + 16 * ((k + o) & 7);
+                out[q] = lo[k];
+                out[q + 128] = hi[k];
+            }
+        }
+    }
+    if (any) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = i + 16 * ((k + o) & 7);
+            if (col_lo[k]) atomicAdd(&lds.hist_warped[q], col_lo[k]);
+            if (col_hi[k]) atomicAdd(&lds.hist_warped[q + 128], col_hi[k]);
+        }
+    }
+}
+
+// The part that arrived last, wavefront 0: the three 256-element trees of AddVectorPairwiseKernel (NMI.cu:295-339) side
+// by side in DPP rows 0 (render marginal), 1 (frame marginal = sum of the K column partials), 2 (joint row sums), then
+// the score.  Every load of handed-off bytes is an sc1 load (they were sc1 stores of other workgroups).
+template <int K>
+__device__ __forceinline__ void final_split(const GridArgs &a, const SplitSlab *slab, int lane, int p, int w, int s,
+                                            unsigned long long &prev_key)
+{
+    const int i = lane & 15, r = lane >> 4;
+    uint32_t cl[8], ch[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cl[k] = ch[k] = 0;
+    if (r == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            cl[k] = load_sc1(&slab->hist_render[i + 16 * k]);
+            ch[k] = load_sc1(&slab->hist_render[i + 16 * k + 128]);
+        }
+    } else if (r == 1) {
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                cl[k] += load_sc1(&slab->hw_part[j][i + 16 * k]);
+                ch[k] += load_sc1(&slab->hw_part[j][i + 16 * k + 128]);
+            }
+    }
+    float lo[8], hi[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        lo[k] = a.table[cl[k]];  // rows 2, 3 fetch table[0] = 0
+        hi[k] = a.table[ch[k]];
+    }
+    if (r == 2) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            lo[k] = load_sc1(&slab->row_sums[i + 16 * k]);
+            hi[k] = load_sc1(&slab->row_sums[i + 16 * k + 128]);
+        }
+    }
+    const float x = row_tree_16(lane_tree_16(lo, hi));
+    const float a1 = __shfl(x, 0, 64), a2 = __shfl(x, 16, 64), a3 = __shfl(x, 32, 64);
+    if (a.dbg_h1 || a.dbg_h2) {
+        for (int t = lane; t < kBins; t += 64) {
+            if (a.dbg_h1) a.dbg_h1[t] = load_sc1(&slab->hist_render[t]);
+            if (a.dbg_h2) {
+                uint32_t c = 0;
+                for (int j = 0; j < K; ++j) c += load_sc1(&slab->hw_part[j][t]);
+                a.dbg_h2[t] = c;
+            }
+        }
+    }
+    if (lane == 0) commit_score(a, p, w, s, a1, a2, a3, prev_key);
+}
+
+}  // namespace
+
+// Unit u of a launch = (candidate, part).  Candidates are taken in groups of 8, one per XCD (workgroups are dealt to the
+// XCDs round-robin: blocks b and b + 8 share one), and the K parts of a candidate are the blocks b, b + 8, ... of that
+// XCD, so they read the pair from one L2.  Placement is a speed matter only.
+template <int K, bool FAST>
+__global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_split_kernel(GridArgs a, int use_bg)
+{
+    __shared__ SplitLds<K> lds;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    if (blockIdx.x == 0 && tid == 0 && a.reset_key) *a.reset_key = 0ull;  // next launch's slot; idle during this one
+    {
+        uint4 *j4 = reinterpret_cast<uint4 *>(lds.joint);
+        const uint4 z = {0, 0, 0, 0};
+        for (int k = tid; k < SplitLds<K>::kRows * kBins / 4; k += kBlock) j4[k] = z;
+    }
+    if (tid < kBins) lds.hist_warped[tid] = 0;
+    __syncthreads();
+
+    const int total = a.S_local * a.Wn;
+    const int units = ((total + 7) >> 3) * 8 * K;
+    unsigned long long prev_key = 0;
+    for (int u = blockIdx.x; u < units; u += gridDim.x) {
+        const int x = u & 7, t = u >> 3;
+        const int part = t % K, p = (t / K) * 8 + x;
+        if (p >= total) continue;  // workgroup-uniform
+        const int w = p / a.S_local, s = p - w * a.S_local;
+        SplitSlab *slab = a.slabs + p;
+
+        if (a.phase_mask & 1)
+            histogram_split<K, FAST>(lds.joint, a, a.render_stack + (size_t)s * a.npix, a.warp_stack + (size_t)w * a.npix, tid, part,
+                                     use_bg != 0);
+        __syncthreads();
+        decode_split<K>(lds, a, slab, part, wave, lane);
+        __syncthreads();
+        if (tid < kBins) {
+            store_sc1(&slab->hw_part[part][tid], lds.hist_warped[tid]);
+            lds.hist_warped[tid] = 0;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its slab stores have left before the ticket is drawn
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned int arrived = __hip_atomic_fetch_add(&slab->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool last = arrived == (unsigned int)(K - 1);
+            if (last) __hip_atomic_store(&slab->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // all K arrived: next launch
+            lds.is_last = last ? 1u : 0u;
+        }
+        __syncthreads();
+        if (lds.is_last && wave == 0) final_split<K>(a, slab, lane, p, w, s, prev_key);
+        // wavefront 0 writes is_last again only after this final phase (tid 0 is one of its lanes); the other wavefronts
+        // meanwhile touch only the (already cleared) counters of the next unit.
+    }
+    if (tid == 0 && !(a.phase_mask & 16)) publish_winner(a, prev_key);
+}
+
+int split_workgroups(int candidates, int parts) { return ((candidates + 7) / 8) * 8 * parts; }
+
+template <int K>
+static void launch_split_k(const GridArgs &a, dim3 grid, dim3 block, bool use_bg, hipStream_t stream)
+{
+    const bool fast = use_bg && a.shift == 0;
+    if (fast)
+        hipLaunchKernelGGL((nmi_split_kernel<K, true>), grid, block, 0, stream, a, 1);
+    else
+        hipLaunchKernelGGL((nmi_split_kernel<K, false>), grid, block, 0, stream, a, use_bg ? 1 : 0);
+}
+
+hipError_t launch_split(const GridArgs &a, int parts, int workgroups, bool use_bg, hipStream_t stream)
+{
+    if (!a.slabs || workgroups <= 0 || (workgroups & 7)) return hipErrorInvalidValue;
+    dim3 grid(workgroups), block(kBlock);
+    switch (parts) {
+    case 2: launch_split_k<2>(a, grid, block, use_bg, stream); break;
+    case 4: launch_split_k<4>(a, grid, block, use_bg, stream); break;
+    case 8: launch_split_k<8>(a, grid, block, use_bg, stream); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace nmi

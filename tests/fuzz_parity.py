@@ -4,7 +4,8 @@
 Content is drawn to reach every branch of the histogram phase: textured, uniform noise, posterised (bins above 65,535),
 flat bands / blocks in one or both stacks (folding, side counters, more flat pairs than side counters), zero regions
 with the background rule off, reduced bin counts, both render orientations.  For every case the whole rating table must
-agree within 1e-5 and the winner (index and score) must be the oracle's.  Test infrastructure (it calls the oracle):
+EQUAL the oracle's (rounded term mode: same fp32 operations in the same order) and the winner (index and score) must be
+the oracle's; the libm-mode oracle (log2f as written) is kept as a <= 1e-5 cross-check.  Test infrastructure (it calls the oracle):
 imported by tests/test_gpu_parity.py; for longer campaigns run  python tests/fuzz_parity.py [cases] [seed]  on a GPU box.
 """
 import os, sys, time
@@ -19,7 +20,7 @@ from oracle import binding as ob
 SHAPES = [(640, 480), (848, 480), (320, 240), (960, 540), (64, 48), (100, 75), (333, 100), (32, 2), (1280, 720)]
 
 
-def run(cases=200, seed=1, verbose=True):
+def run(cases=200, seed=1, verbose=True, options=None):
     rng = np.random.default_rng(seed)
 
     def content(kind, n, h, w):
@@ -58,18 +59,23 @@ def run(cases=200, seed=1, verbose=True):
         bins = int(rng.choice([256, 256, 64, 16]))
         bg, bu, mode = bool(rng.random() < 0.8), bool(rng.random() < 0.7), int(rng.integers(0, 2))
         shift = {256: 0, 64: 2, 16: 4}[bins]
-        ref = np.array([[ob.eval_pair(rs[s], ws[v], shift=shift, use_bg=bg, render_bottom_up=bu, mode=mode) for s in range(S)]
-                        for v in range(Wn)], np.float32)
-        ibest, vbest = ob.find_max(ref)
+        with ob.rounded():
+            ref, ibest, vbest = ob.search_grid(rs, ws, shift=shift, use_bg=bg, render_bottom_up=bu, mode=mode, threads=8)
+        libm, _, _ = ob.search_grid(rs, ws, shift=shift, use_bg=bg, render_bottom_up=bu, mode=mode, threads=8)
         with nmi.NmiContext(w, h, bins=bins, mode=mode, use_bg=bg, render_bottom_up=bu) as ctx:
+            for opt, val in (options or {}).items():
+                ctx.set_option(opt, val)
             ratings = torch.empty((Wn, S), dtype=torch.float32, device="cuda")
             idx, val = ctx.search_grid(torch.from_numpy(rs).cuda(), torch.from_numpy(ws).cuda(), ratings=ratings)
             got = ratings.cpu().numpy()
-        err = float(np.abs(got - ref).max())
+        same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+        err = 0.0 if same.all() else float(np.nanmax(np.abs(got - ref)))
         worst = max(worst, err)
         tag = f"case {c} (seed {seed}): {w}x{h} S={S} Wn={Wn} kinds=({kr},{kw}) bins={bins} bg={bg} bu={bu} mode={mode}"
-        assert err <= 1e-5, (tag, err)
-        assert idx == ibest and abs(val - float(vbest)) <= 1e-5, (tag, idx, ibest, val, vbest)
+        assert same.all(), (tag, err)
+        assert (idx, val) == (ibest, vbest), (tag, idx, ibest, val, vbest)
+        fin = np.isfinite(libm)
+        assert np.abs(got[fin] - libm[fin]).max(initial=0.0) <= 1e-5 * max(1.0, float(np.abs(libm[fin]).max(initial=0.0))), tag
         if verbose and c % 20 == 19:
             print(f"{c + 1} cases ok, worst |score error| {worst:.2e}, {time.time() - t0:.0f} s", flush=True)
     return worst

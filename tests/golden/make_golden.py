@@ -45,6 +45,11 @@ def pairs():
     }
 
 
+def _rounded(fn):
+    with oc.rounded():
+        return fn()
+
+
 def main():
     out = {}
     names = []
@@ -68,8 +73,14 @@ def main():
                     sn = onp.score_from_hist(j, h1, h2, W * H, mode)
                     assert abs(float(s) - float(sn)) <= 1e-6 * max(1.0, abs(float(s))), (tag, mode, s, sn)
                     out[f"{tag}/score_mode{mode}"] = np.float32(s)
+                    with oc.rounded():  # per-bin log2 correctly rounded: what the GPU tests compare with ==
+                        sr, sums_r = oc.score_from_hist(j, h1, h2, W * H, mode)
+                    out[f"{tag}/score_mode{mode}_rounded"] = np.float32(sr)
                 out[f"{tag}/sums"] = sums
+                out[f"{tag}/sums_rounded"] = sums_r
                 out[f"{tag}/score64_bins64"] = np.float32(oc.eval_pair(r, w, 2, bool(bg), bool(bu), 1))
+                with oc.rounded():
+                    out[f"{tag}/score64_bins64_rounded"] = np.float32(oc.eval_pair(r, w, 2, bool(bg), bool(bu), 1))
     out["names"] = np.array(names)
     np.savez_compressed(os.path.join(HERE, "pairs_64x48.npz"), **out)
 
@@ -78,9 +89,12 @@ def main():
     ratings, idx, best = oc.search_grid(wl["render_stack"], wl["warp_stack"])
     rn, idxn, bestn = onp.search_grid(wl["render_stack"], wl["warp_stack"])
     assert idx == idxn and np.allclose(ratings, rn, atol=1e-6)
+    with oc.rounded():
+        ratings_r, idx_r, best_r = oc.search_grid(wl["render_stack"], wl["warp_stack"])
     np.savez_compressed(os.path.join(HERE, "grid_64x48.npz"), render_stack=wl["render_stack"],
                         warp_stack=wl["warp_stack"], ratings=ratings, best_index=np.int64(idx),
-                        best_score=np.float32(best))
+                        best_score=np.float32(best), ratings_rounded=ratings_r, best_index_rounded=np.int64(idx_r),
+                        best_score_rounded=np.float32(best_r))
 
     # Known answers at full frame size (inputs are regenerated from the seed, only the expectations are stored).
     a, b = sy.uniform_pair(640, 480, 1234)
@@ -88,6 +102,9 @@ def main():
         "uniform_640x480_seed1234_suc_topdown": np.float32(oc.eval_pair(a, b, 0, True, False, 1)),
         "uniform_640x480_seed1234_enmi_topdown": np.float32(oc.eval_pair(a, b, 0, True, False, 0)),
         "uniform_640x480_seed1234_suc_bottomup": np.float32(oc.eval_pair(a, b, 0, True, True, 1)),
+        "uniform_640x480_seed1234_suc_topdown_rounded": np.float32(_rounded(lambda: oc.eval_pair(a, b, 0, True, False, 1))),
+        "uniform_640x480_seed1234_enmi_topdown_rounded": np.float32(_rounded(lambda: oc.eval_pair(a, b, 0, True, False, 0))),
+        "uniform_640x480_seed1234_suc_bottomup_rounded": np.float32(_rounded(lambda: oc.eval_pair(a, b, 0, True, True, 1))),
         "uniform_640x480_seed1234_crc": np.uint64(int(a.astype(np.uint64).sum()) * 1000003 + int(b.astype(np.uint64).sum())),
     }
     np.savez_compressed(os.path.join(HERE, "kat_640x480.npz"), **kat)

@@ -1,9 +1,12 @@
 """GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on identical inputs.
 
-Bars: integer work (joint / marginal histograms, arg-max index) bit-exact; the three fp32 entropy sums within
-2e-6; the score within 1e-5 (BASELINE.json north_star).  The oracle is "parity unpinned" against the reference
-itself (no golden vectors exist there, oracle/nmi_oracle.c header); the analytic known answers are checked on
-the GPU directly as well."""
+Bars: integer work (joint / marginal histograms, arg-max index) bit-exact.  Floating point: against the oracle in its
+"rounded" term mode (oracle/nmi_oracle.c nmi_oracle_bin_term: the fp64 log2 rounded once to fp32 -- the same value the
+product's per-count table holds, checked entry by entry in test_term_table_equals_oracle) every entropy sum, every
+rating and every winner is compared with ==: same fp32 operations in the reference's order (NMI.cu:270-339).  Against
+the oracle's libm mode (the expression as written, log2f of this host) the north_star's 1e-5 is kept as a cross-check.
+The oracle is "parity unpinned" against the reference's CUDA kernels (no golden vectors exist there and they cannot be
+built here, oracle/nmi_oracle.c header); the analytic known answers are checked on the GPU directly as well."""
 import numpy as np
 import pytest
 
@@ -12,7 +15,7 @@ from conftest import dense_joint
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
-SCORE_TOL = 1e-5  # north_star: "within 1e-5"
+SCORE_TOL = 1e-5  # north_star: "within 1e-5" -- only for comparisons with the libm-mode oracle and stored fixtures
 SUM_TOL = 2e-6
 
 
@@ -29,6 +32,25 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
+# Kernel selection for small grids (NMI_OPT_SPLIT): -1 automatic (K = 8 / 4 / 2 workgroups per candidate when the grid
+# leaves compute units idle), 0 the one-workgroup-per-candidate kernel only, 8 / 4 / 2 forced.  Tests that take this
+# fixture run once per mode; results must be identical bit for bit.
+@pytest.fixture(params=[-1, 0, 8, 4, 2], ids=lambda m: {-1: "auto", 0: "nosplit"}.get(m, f"split{m}"))
+def split_mode(request, nmi):
+    from orbslam2_nmi_amd import capi
+    capi.NmiContext.default_options = {capi.NmiContext.OPT_SPLIT: request.param}
+    yield request.param
+    capi.NmiContext.default_options = {}
+
+
+@pytest.fixture(params=[-1, 0], ids=["auto", "nosplit"])
+def split_mode2(request, nmi):
+    from orbslam2_nmi_amd import capi
+    capi.NmiContext.default_options = {capi.NmiContext.OPT_SPLIT: request.param}
+    yield request.param
+    capi.NmiContext.default_options = {}
+
+
 def check_pair(nmi, oc, r, w, bins=256, mode=1, bg=True, bu=True):
     h, wd = r.shape
     shift = {256: 0, 128: 1, 64: 2, 32: 3, 16: 4}[bins]
@@ -36,16 +58,34 @@ def check_pair(nmi, oc, r, w, bins=256, mode=1, bg=True, bu=True):
         s, j, h1, h2, sums = ctx.eval_pair_debug(dev(r), dev(w))
         s2 = ctx.eval_pair(dev(r), dev(w))
     jo, h1o, h2o = oc.joint_hist(r, w, shift, bg, bu)
-    so, sums_o = oc.score_from_hist(jo, h1o, h2o, h * wd, mode)
     assert (j == jo).all(), "joint histogram differs"
     assert (h1 == h1o).all() and (h2 == h2o).all(), "marginal histogram differs"
-    assert np.abs(sums - sums_o).max() <= SUM_TOL * max(1.0, np.abs(sums_o).max()), (sums, sums_o)
-    assert abs(float(s) - float(so)) <= SCORE_TOL, (s, so)
-    assert s == s2
+    with oc.rounded():
+        so, sums_o = oc.score_from_hist(jo, h1o, h2o, h * wd, mode)
+    assert (sums.view(np.uint32) == sums_o.view(np.uint32)).all(), (sums, sums_o)          # bit for bit
+    assert np.float32(s).view(np.uint32) == np.float32(so).view(np.uint32) or (np.isnan(s) and np.isnan(so)), (s, so)
+    sl, _ = oc.score_from_hist(jo, h1o, h2o, h * wd, mode)                                  # libm log2f cross-check
+    assert abs(float(s) - float(sl)) <= SCORE_TOL * max(1.0, abs(float(sl))) or (np.isnan(s) and np.isnan(sl)), (s, sl)
+    assert s == s2 or (np.isnan(s) and np.isnan(s2))
     return s
 
 
-def test_golden_pairs_all_switches(nmi, golden_pairs):
+@pytest.mark.parametrize("shape", [(640, 480), (960, 540), (848, 480), (64, 48), (333, 251), (1, 1), (4096, 4096)])
+def test_term_table_equals_oracle(nmi, shape):
+    """The per-count term table (c/len)*log2(c/len), len = W*H (NMI.cu:242-263): every entry equals the oracle's
+    correctly rounded evaluation, and the libm evaluation differs from it by at most one fp32 rounding of the product."""
+    from oracle import binding as oc
+    w, h = shape
+    with nmi.NmiContext(w, h) as ctx:
+        got = ctx.term_table()
+    with oc.rounded():
+        exp = oc.term_table(w * h)
+    assert got.shape == exp.shape and (got.view(np.uint32) == exp.view(np.uint32)).all()
+    libm = oc.term_table(w * h)
+    assert np.abs(libm - exp).max() <= 6e-8 and got[0] == 0 and got[-1] == 0
+
+
+def test_golden_pairs_all_switches(nmi, golden_pairs, split_mode):
     from oracle import binding as oc
     g = golden_pairs
     for name in g["names"]:
@@ -57,18 +97,23 @@ def test_golden_pairs_all_switches(nmi, golden_pairs):
                     s, j, h1, h2, sums = ctx.eval_pair_debug(dev(r), dev(w))
                 assert (j == dense_joint(g, tag)).all(), tag
                 assert (h1 == g[f"{tag}/hist_render"]).all() and (h2 == g[f"{tag}/hist_warped"]).all(), tag
+                assert (sums == g[f"{tag}/sums_rounded"]).all(), tag
+                assert s == g[f"{tag}/score_mode1_rounded"], tag
                 assert np.abs(sums - g[f"{tag}/sums"]).max() <= SUM_TOL * max(1, np.abs(g[f"{tag}/sums"]).max()), tag
                 assert abs(float(s) - float(g[f"{tag}/score_mode1"])) <= SCORE_TOL, tag
                 with nmi.NmiContext(64, 48, mode=nmi.MODE_ENMI, use_bg=bool(bg), render_bottom_up=bool(bu)) as ctx:
                     e = ctx.eval_pair(dev(r), dev(w))
                 ref = float(g[f"{tag}/score_mode0"])
                 assert (np.isnan(ref) and np.isnan(e)) or abs(float(e) - ref) <= SCORE_TOL * max(1, abs(ref)), tag
+                refr = g[f"{tag}/score_mode0_rounded"]
+                assert (np.isnan(refr) and np.isnan(e)) or e == refr, tag
                 with nmi.NmiContext(64, 48, bins=64, use_bg=bool(bg), render_bottom_up=bool(bu)) as ctx:
                     s64 = ctx.eval_pair(dev(r), dev(w))
                 assert abs(float(s64) - float(g[f"{tag}/score64_bins64"])) <= SCORE_TOL, tag
+                assert s64 == g[f"{tag}/score64_bins64_rounded"], tag
 
 
-def test_known_answers_640x480(nmi, golden_kat):
+def test_known_answers_640x480(nmi, golden_kat, split_mode):
     from orbslam2_nmi_amd import synthetic as sy
     a, b = sy.uniform_pair(640, 480, 1234)
     with nmi.NmiContext(640, 480, render_bottom_up=False) as ctx:
@@ -82,11 +127,12 @@ def test_known_answers_640x480(nmi, golden_kat):
         assert ctx.eval_pair(dev(a), dev(a)) == np.float32(2.0)
     with nmi.NmiContext(640, 480) as ctx:
         assert abs(float(ctx.eval_pair(dev(a), dev(b))) - float(golden_kat["uniform_640x480_seed1234_suc_bottomup"])) <= 2e-7
+        assert ctx.eval_pair(dev(a), dev(b)) == golden_kat["uniform_640x480_seed1234_suc_bottomup_rounded"]
 
 
 @pytest.mark.parametrize("shape", [(640, 480), (960, 540), (848, 480), (64, 48), (16, 4)])
 @pytest.mark.parametrize("kind", ["smooth", "uniform"])
-def test_pair_vs_oracle_sizes(nmi, shape, kind):
+def test_pair_vs_oracle_sizes(nmi, shape, kind, split_mode):
     from oracle import binding as oc
     from orbslam2_nmi_amd import synthetic as sy
     w, h = shape
@@ -102,7 +148,7 @@ def test_pair_vs_oracle_sizes(nmi, shape, kind):
 
 
 @pytest.mark.parametrize("shape", [(37, 23), (641, 7), (100, 100), (17, 1), (1, 1), (333, 251)])
-def test_ragged_widths_take_the_generic_path(nmi, shape):
+def test_ragged_widths_take_the_generic_path(nmi, shape, split_mode):
     from oracle import binding as oc
     w, h = shape
     rng = np.random.default_rng(w * 1000 + h)
@@ -114,7 +160,7 @@ def test_ragged_widths_take_the_generic_path(nmi, shape):
 
 
 @pytest.mark.parametrize("bins", [256, 128, 64, 32, 16])
-def test_bins(nmi, bins):
+def test_bins(nmi, bins, split_mode):
     from oracle import binding as oc
     from orbslam2_nmi_amd import synthetic as sy
     B = sy.scene(320, 240, 12)
@@ -122,7 +168,7 @@ def test_bins(nmi, bins):
     check_pair(nmi, oc, B, sy.camera_frame(B, 13), bins=bins, bg=False, bu=False)
 
 
-def test_counter_wrap_cases(nmi):
+def test_counter_wrap_cases(nmi, split_mode):
     """Bins above 65535 hits: the packed 16-bit LDS counters wrap and must be reconstructed exactly."""
     from oracle import binding as oc
     w, h = 960, 540  # 518400 pixels: up to 7 wraps of one counter
@@ -157,7 +203,7 @@ def _banded(h, w, values, band):
     return np.repeat(rows[:, None], w, axis=1)
 
 
-def test_flat_regions_are_folded_exactly(nmi):
+def test_flat_regions_are_folded_exactly(nmi, split_mode):
     """Regions where both images are constant are folded into weighted adds / 32-bit side counters (fold_flat_chunk):
     few pairs, more distinct pairs than side counters, flat next to texture, flat bins that also collect textured hits
     and exceed 65535, every switch that changes the pixel rule."""
@@ -197,7 +243,7 @@ def test_flat_regions_are_folded_exactly(nmi):
         check_pair(nmi, oc, r, f, bins=32, bu=True)
 
 
-def test_flat_regions_in_a_grid(nmi):
+def test_flat_regions_in_a_grid(nmi, split_mode2):
     """The grid kernel on stacks with large flat regions: rating table and winner equal the oracle's, with folding on
     and off (NMI_OPT_PHASE_MASK bit 2), so the two code paths are compared with each other too."""
     from oracle import binding as oc
@@ -209,21 +255,26 @@ def test_flat_regions_in_a_grid(nmi):
     ws[:, -(h // 3):] = 255
     ws[2, : h // 2] = 0
     rs[3, h // 2:] = 255           # render 3 over warp 2: flat (255, 0) as well
-    ref = np.array([[oc.eval_pair(rs[s], ws[v]) for s in range(S)] for v in range(Wn)], np.float32)
+    with oc.rounded():
+        ref = np.array([[oc.eval_pair(rs[s], ws[v]) for s in range(S)] for v in range(Wn)], np.float32)
     ibest, vbest = oc.find_max(ref)
     with nmi.NmiContext(w, h) as ctx:
         for variant in (3, 0, 1, 4):       # every wrap-handling variant meets the flat regions, with and without folding
-            ctx.set_option(ctx.OPT_HIST_VARIANT, variant)
+            try:
+                ctx.set_option(ctx.OPT_HIST_VARIANT, variant)
+            except nmi.NmiError as e:      # 0 / 2 / 4 exist only in -DNMI_BUILD_ABLATIONS builds
+                assert e.code == -2 and variant in (0, 4)
+                continue
             for mask in ((3,) if variant == 4 else (3, 7)):  # bit 2 is a different ablation switch in the pipelined kernel
                 ctx.set_option(ctx.OPT_PHASE_MASK, mask)
                 ratings = torch.full((Wn, S), -3.0, dtype=torch.float32, device="cuda")
                 idx, val = ctx.search_grid(dev(rs), dev(ws), ratings=ratings)
                 got = ratings.cpu().numpy()
-                assert np.abs(got - ref).max() <= SCORE_TOL, (variant, mask)
-                assert idx == ibest and abs(val - float(vbest)) <= SCORE_TOL, (variant, mask)
+                assert (got == ref).all(), (variant, mask)
+                assert (idx, val) == (ibest, vbest), (variant, mask)
 
 
-def test_grid_golden(nmi, golden_grid):
+def test_grid_golden(nmi, golden_grid, split_mode):
     g = golden_grid
     rs, ws = g["render_stack"], g["warp_stack"]
     with nmi.NmiContext(64, 48) as ctx:
@@ -233,6 +284,8 @@ def test_grid_golden(nmi, golden_grid):
     assert idx == int(g["best_index"]) == idx2
     assert abs(float(best) - float(g["best_score"])) <= SCORE_TOL and best == best2
     assert np.abs(ratings.cpu().numpy() - g["ratings"]).max() <= SCORE_TOL
+    assert (ratings.cpu().numpy() == g["ratings_rounded"]).all()
+    assert idx == int(g["best_index_rounded"]) and best == g["best_score_rounded"]
 
 
 def grid_vs_oracle(nmi, wl, w, h, **kw):
@@ -242,12 +295,12 @@ def grid_vs_oracle(nmi, wl, w, h, **kw):
     with nmi.NmiContext(w, h, render_bottom_up=wl["bottom_up"], **kw) as ctx:
         ratings = torch.full((Wn, S), -7.0, dtype=torch.float32, device="cuda")
         idx, best = ctx.search_grid(dev(rs), dev(ws), ratings)
-    ro, io, bo = oc.search_grid(rs, ws, render_bottom_up=wl["bottom_up"], threads=16,
-                                use_bg=kw.get("use_bg", True), mode=kw.get("mode", 1))
+    with oc.rounded():
+        ro, io, bo = oc.search_grid(rs, ws, render_bottom_up=wl["bottom_up"], threads=16,
+                                    use_bg=kw.get("use_bg", True), mode=kw.get("mode", 1))
     r = ratings.cpu().numpy()
-    assert np.abs(r - ro).max() <= SCORE_TOL
-    # arg-max: identical index; if the oracle's top two are closer than fp32 noise the GPU may pick the other
-    assert idx == io or abs(float(ro.reshape(-1)[idx]) - float(bo)) <= 2e-7, (idx, io)
+    assert (r.view(np.uint32) == ro.view(np.uint32)).all(), np.abs(r - ro).max()   # the whole table, bit for bit
+    assert (idx, best) == (io, bo)
     assert best == r.reshape(-1)[idx]
     gi, gb = oc.find_max(r)  # arg-max rule applied to the GPU's own table
     assert (gi, gb) == (idx, best)
@@ -281,13 +334,14 @@ def test_grid_config4_shard_shape(nmi):
     with nmi.NmiContext(848, 480) as ctx:
         t = torch.zeros(64, 64, device="cuda")
         key = ctx.search_grid_shard(dev(rs), 64 * rank, s_total, dev(ws), t)
-    ro, io, bo = oc.search_grid(rs, ws, threads=16)
-    assert np.abs(t.cpu().numpy() - ro).max() <= SCORE_TOL
+    with oc.rounded():
+        ro, io, bo = oc.search_grid(rs, ws, threads=16)
+    assert (t.cpu().numpy() == ro).all()
     w, s = divmod(io, 64)
     assert nmi.key_unpack(key) == (w * s_total + 64 * rank + s, bo)
 
 
-def test_full_size_properties_without_oracle(nmi):
+def test_full_size_properties_without_oracle(nmi, split_mode):
     """Size-independent properties at full size (no oracle): permutation invariance of the histogram under a common
     pixel permutation, symmetry of SUC in its two images, identical pair -> 1, and arg-max consistency."""
     rng = np.random.default_rng(123)
@@ -314,7 +368,7 @@ def test_full_size_properties_without_oracle(nmi):
         assert tt[0, 1] == 1.0 and tt[1, 0] == 1.0 and tt[1, 2] == 1.0 and tt[0, 0] == s_ba and tt[1, 1] == s_ab
 
 
-def test_grid_switches_and_ties(nmi):
+def test_grid_switches_and_ties(nmi, split_mode):
     from orbslam2_nmi_amd import synthetic as sy
     wl = sy.workload(160, 120, 8, 12, seed=5, bottom_up=False)
     grid_vs_oracle(nmi, wl, 160, 120, use_bg=False)
@@ -333,7 +387,7 @@ def test_grid_switches_and_ties(nmi):
     assert (r.reshape(-1) == best).sum() == 9
 
 
-def test_grid_degenerate_tables(nmi):
+def test_grid_degenerate_tables(nmi, split_mode):
     # every candidate scores 0 (constant renders): winner = first cell with value 0 -> index 0
     rs = np.full((3, 48, 64), 255, np.uint8)
     ws = np.random.default_rng(1).integers(0, 256, (2, 48, 64), dtype=np.uint8)
@@ -346,7 +400,7 @@ def test_grid_degenerate_tables(nmi):
         assert idx == 0
 
 
-def test_shard_keys_compose(nmi):
+def test_shard_keys_compose(nmi, split_mode):
     """Sharding along the render axis: max over per-shard keys == unsharded winner."""
     from orbslam2_nmi_amd import synthetic as sy
     wl = sy.workload(160, 120, 8, 6, seed=9)
@@ -377,7 +431,7 @@ def test_shard_keys_compose(nmi):
             ctx.search_grid_shard(rs, 0, 8, ws, w_offset=3, wn_total=6)  # block sticks out of the grid
 
 
-def test_reuse_of_one_context_is_clean(nmi):
+def test_reuse_of_one_context_is_clean(nmi, split_mode):
     """The LDS histogram is re-zeroed while it is decoded; repeated and interleaved calls must not leak counts."""
     from oracle import binding as oc
     rng = np.random.default_rng(3)
@@ -385,13 +439,15 @@ def test_reuse_of_one_context_is_clean(nmi):
         for _ in range(5):
             r = rng.integers(0, 256, (48, 64), dtype=np.uint8)
             f = rng.integers(0, 256, (48, 64), dtype=np.uint8)
-            assert abs(float(ctx.eval_pair(dev(r), dev(f))) - float(oc.eval_pair(r, f))) <= SCORE_TOL
+            with oc.rounded():
+                assert ctx.eval_pair(dev(r), dev(f)) == oc.eval_pair(r, f)
         rs = rng.integers(0, 256, (40, 48, 64), dtype=np.uint8)
         ws = rng.integers(0, 256, (30, 48, 64), dtype=np.uint8)  # 1200 candidates > one pass of workgroups
         t = torch.zeros(30, 40, device="cuda")
         ctx.search_grid(dev(rs), dev(ws), t)
-        ro, _, _ = oc.search_grid(rs, ws, threads=16)
-        assert np.abs(t.cpu().numpy() - ro).max() <= SCORE_TOL
+        with oc.rounded():
+            ro, _, _ = oc.search_grid(rs, ws, threads=16)
+        assert (t.cpu().numpy() == ro).all()
 
 
 def test_rccl_world_size_1(nmi):
@@ -406,6 +462,84 @@ def test_rccl_world_size_1(nmi):
             assert ctx.search_grid_rccl(rs, 0, 4, ws, comm) == ref
         finally:
             capi.rccl_comm_destroy(comm)
+
+
+def test_rccl_empty_shards_do_not_leak_a_stale_winner(nmi):
+    """A rank whose block is empty (fewer renders than ranks) still takes part in the all-reduce.  The reduced winner
+    must never land in one of the context's ping-pong key slots: the next search on that rank starts its arg-max from
+    zero.  Sequence: empty / non-empty calls interleaved, a lower-scoring grid after a higher-scoring one, the
+    warp-axis block form; every non-empty result must equal the plain search of the same block."""
+    from orbslam2_nmi_amd import capi, synthetic as sy
+    rng = np.random.default_rng(8)
+    hi_r = rng.integers(0, 256, (4, 48, 64), dtype=np.uint8)
+    hi_w = rng.integers(0, 256, (3, 48, 64), dtype=np.uint8)
+    hi_w[1] = hi_r[2][::-1]                                       # identical after the bottom-up flip: score 1 at w=1, s=2
+    lo_r = rng.integers(0, 256, (4, 48, 64), dtype=np.uint8)      # unrelated noise: every score below 1
+    lo_w = rng.integers(0, 256, (3, 48, 64), dtype=np.uint8)
+    rs_hi, ws_hi, rs_lo, ws_lo = dev(hi_r), dev(hi_w), dev(lo_r), dev(lo_w)
+    empty = torch.zeros((0, 48, 64), dtype=torch.uint8, device="cuda")
+    with nmi.NmiContext(64, 48) as ctx:
+        ref_hi, ref_lo = ctx.search_grid(rs_hi, ws_hi), ctx.search_grid(rs_lo, ws_lo)
+        assert ref_hi == (1 * 4 + 2, np.float32(1.0)) and 0 < ref_lo[1] < 0.9
+        comm = ctx.rccl_comm_init(capi.rccl_unique_id(), 0, 1)
+        try:
+            for _ in range(2):
+                assert ctx.search_grid_rccl(rs_hi, 0, 4, ws_hi, comm) == ref_hi
+                assert ctx.search_grid_rccl(empty, 0, 4, ws_hi, comm) == (-1, np.float32(0))   # this rank holds no renders
+                assert ctx.search_grid_rccl(rs_lo, 0, 4, ws_lo, comm) == ref_lo                  # not hi's stale key
+                assert ctx.search_grid_rccl(empty, 4, 4, ws_hi, comm) == (-1, np.float32(0))
+                assert ctx.search_grid_rccl(empty, 0, 0, ws_hi, comm) == (-1, np.float32(0))
+                assert ctx.search_grid(rs_lo, ws_lo) == ref_lo                                    # and the plain entry too
+            # warp-axis block (S < ranks): warps [1, 3) of 3 with global indices
+            blk = ctx.search_grid_rccl(rs_hi, 0, 4, ws_hi[1:3].contiguous(), comm, w_offset=1, wn_total=3)
+            key = ctx.search_grid_shard(rs_hi, 0, 4, ws_hi[1:3].contiguous(), w_offset=1, wn_total=3)
+            assert blk == nmi.key_unpack(key)
+            assert ctx.search_grid_rccl(rs_hi, 0, 4, ws_hi[:0].contiguous(), comm, w_offset=0, wn_total=3) == (-1, np.float32(0))
+            assert ctx.search_grid_rccl(rs_lo, 0, 4, ws_lo, comm) == ref_lo
+        finally:
+            capi.rccl_comm_destroy(comm)
+
+
+def test_alternating_grid_shapes(nmi):
+    """A coarse-to-fine search alternates between grid shapes (translation level S x 1, rotation level 1 x Wn, full
+    levels): the per-shape visiting orders are cached (more shapes than cache entries here, so entries are evicted
+    too) and results must not depend on the order of calls.  Checked against the same context with tiling off."""
+    rng = np.random.default_rng(31)
+    rs = dev(rng.integers(0, 256, (24, 48, 64), dtype=np.uint8))
+    ws = dev(np.clip(rs.cpu().numpy().astype(int) + rng.integers(-40, 40, (24, 48, 64)), 0, 255).astype(np.uint8))
+    shapes = [(24, 24), (24, 13), (13, 24), (20, 20), (17, 19), (19, 17), (24, 12), (12, 24), (16, 18), (18, 16), (23, 23), (22, 21),
+              (21, 22), (15, 20), (20, 15), (14, 22), (22, 14), (24, 11), (11, 24), (13, 23), (27 // 1 - 3, 1), (1, 24), (3, 9)]
+    with nmi.NmiContext(64, 48) as ref_ctx:
+        ref_ctx.set_option(ref_ctx.OPT_XCD_TILING, 0)
+        ref_ctx.set_option(ref_ctx.OPT_SPLIT, 0)
+        expect = {sh: ref_ctx.search_grid(rs[:sh[0]].contiguous(), ws[:sh[1]].contiguous()) for sh in shapes}
+    with nmi.NmiContext(64, 48) as ctx:
+        for rep in range(3):
+            for sh in (shapes if rep != 1 else shapes[::-1]):
+                t = torch.zeros(sh[1], sh[0], device="cuda")
+                got = ctx.search_grid(rs[:sh[0]].contiguous(), ws[:sh[1]].contiguous(), t)
+                assert got == expect[sh], (rep, sh)
+                assert t.reshape(-1)[got[0]].item() == got[1]
+
+
+def test_wait_modes_and_result_paths_agree(nmi):
+    """NMI_OPT_WAIT_MODE (spin / yield) and NMI_OPT_RESULT_PATH (mailbox / copy) only change how the host waits."""
+    from orbslam2_nmi_amd import synthetic as sy
+    wl = sy.workload(160, 120, 9, 9, seed=4)
+    rs, ws = dev(wl["render_stack"]), dev(wl["warp_stack"])
+    with nmi.NmiContext(160, 120) as ctx:
+        ref = ctx.search_grid(rs, ws)
+        pair = ctx.eval_pair(rs[0], ws[0])
+        for wait in (0, 1):
+            for path in (1, 0):
+                ctx.set_option(ctx.OPT_WAIT_MODE, wait)
+                ctx.set_option(ctx.OPT_RESULT_PATH, path)
+                for _ in range(3):
+                    assert ctx.search_grid(rs, ws) == ref
+                    assert ctx.eval_pair(rs[0], ws[0]) == pair
+        assert ctx.info()["workgroups_per_launch"] == ctx.info()["compute_units"]
+        ctx.set_option(ctx.OPT_WORKGROUPS, 40)
+        assert ctx.info()["workgroups_per_launch"] == 40 and ctx.search_grid(rs, ws) == ref
 
 
 def test_invalid_arguments_fail_loudly(nmi):
@@ -469,17 +603,22 @@ def test_kernel_variants_agree(nmi, variant):
     rs, ws = wl["render_stack"].copy(), wl["warp_stack"].copy()
     rs[4] = 255                                         # a constant render (76,800 px)...
     ws[7] = 0                                           # ...over a constant frame: one bin gets 76,800 > 65,535 hits
-    ro, io, bo = oc.search_grid(rs, ws, threads=16)
+    with oc.rounded():
+        ro, io, bo = oc.search_grid(rs, ws, threads=16)
     with nmi.NmiContext(320, 240) as ctx:
-        ctx.set_option(ctx.OPT_HIST_VARIANT, variant)
+        try:
+            ctx.set_option(ctx.OPT_HIST_VARIANT, variant)
+        except nmi.NmiError as e:
+            assert e.code == -2 and variant in (0, 4)
+            pytest.skip("ablation variants are not compiled into the shipped library (-DNMI_BUILD_ABLATIONS)")
         ctx.set_option(ctx.OPT_WORKGROUPS, 64)
         t = torch.zeros(30, 9, device="cuda")
         idx, best = ctx.search_grid(dev(rs), dev(ws), t)
-    assert np.abs(t.cpu().numpy() - ro).max() <= SCORE_TOL
-    assert (idx, best) == (io, bo) or abs(float(ro.reshape(-1)[idx]) - float(bo)) <= 2e-7
+    assert (t.cpu().numpy() == ro).all()
+    assert (idx, best) == (io, bo)
 
 
-def test_randomised_shapes_and_switches(nmi):
+def test_randomised_shapes_and_switches(nmi, split_mode):
     """Seeded sweep over frame shapes, switches and value distributions (includes flat regions, zeros, saturated pixels):
     histograms bit-exact, score within tolerance, for every draw."""
     from oracle import binding as oc
@@ -509,7 +648,7 @@ def test_randomised_shapes_and_switches(nmi):
                    bg=bool(rng.integers(0, 2)), bu=bool(rng.integers(0, 2)))
 
 
-def test_empty_grids_and_maximum_frame(nmi):
+def test_empty_grids_and_maximum_frame(nmi, split_mode2):
     """Edge sizes: grids with no candidates give "no winner" (index -1, score 0) without touching the inputs; the largest
     frame the library accepts (4096x4096 = 2^24 pixels, counts still exact in fp32) matches the oracle, wraps included."""
     from oracle import binding as oc
@@ -529,16 +668,20 @@ def test_empty_grids_and_maximum_frame(nmi):
     with nmi.NmiContext(n, n, render_bottom_up=False) as ctx:
         s, j, h1, h2, sums = ctx.eval_pair_debug(dev(r), dev(f))
     jo, h1o, h2o = oc.joint_hist(r, f, 0, True, False)
-    so, sums_o = oc.score_from_hist(jo, h1o, h2o, n * n)
+    with oc.rounded():
+        so, sums_o = oc.score_from_hist(jo, h1o, h2o, n * n)
     assert (j == jo).all() and (h1 == h1o).all() and (h2 == h2o).all()
-    assert j[255, 0] >= (n // 2) ** 2 and abs(float(s) - float(so)) <= SCORE_TOL
+    assert j[255, 0] >= (n // 2) ** 2 and s == so and (sums == sums_o).all()
 
 
 def test_fuzz_campaign_against_the_oracle(nmi):
     """tests/fuzz_parity.py, 250 seeded cases: random grid shapes, frame sizes, switches and content mixes (textured,
     noise, posterised, flat bands / blocks, constant) -- whole rating tables and winners against the C oracle."""
     import fuzz_parity
-    assert fuzz_parity.run(250, seed=11, verbose=False) <= SCORE_TOL
+    assert fuzz_parity.run(250, seed=11, verbose=False) == 0.0   # rating tables equal bit for bit, winners identical
+    # the same campaign's first cases through the one-workgroup-per-candidate kernel only (the grids above are small
+    # enough that the automatic selection scores most of them with the split kernel)
+    assert fuzz_parity.run(60, seed=11, verbose=False, options={nmi.NmiContext.OPT_SPLIT: 0}) == 0.0
 
 
 def test_two_contexts_from_two_threads(nmi):
