@@ -285,6 +285,8 @@ int nmi_last_kernel_ms(nmi_ctx *ctx, float *h_ms);
                                   (lowest latency, occupies the calling core for the search), 1 yields the core between
                                   polls (sched_yield; for hosts whose other threads need the core, e.g. ORB-SLAM2's
                                   LocalMapping / LoopClosing).  NMI_OPT_RESULT_PATH 0 sleeps in hipStreamSynchronize instead. */
+#define NMI_OPT_STAMPS 9       /* profiling tools only: value = device pointer to uint64 [workgroups][8]; workgroups of the
+                                  split kernel store wall-clock stamps (100 MHz) at their phase boundaries there; 0 = off */
 int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value);
 
 /* Introspection. */

@@ -139,6 +139,7 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     a.dbg_sums = dbg_sums;
     a.hist_variant = ctx->hist_variant;
     a.phase_mask = ctx->phase_mask;
+    a.dbg_stamps = ctx->dbg_stamps;
 
     const int64_t total = (int64_t)S_local * Wn;
     if (total == 0) {
@@ -468,12 +469,15 @@ int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value)
         if (value != -1 && value != 0 && value != 2 && value != 4 && value != 8) return NMI_ERR_INVALID_ARGUMENT;
         ctx->split_mode = (int)value;
         return NMI_OK;
+    case NMI_OPT_STAMPS:
+        ctx->dbg_stamps = (unsigned long long *)(uintptr_t)value;
+        return NMI_OK;
     case NMI_OPT_WAIT_MODE:
         if (value < 0 || value > 1) return NMI_ERR_INVALID_ARGUMENT;
         ctx->wait_mode = (int)value;
         return NMI_OK;
     case NMI_OPT_PHASE_MASK:
-        if (value < 0 || value > 31) return NMI_ERR_INVALID_ARGUMENT;
+        if (value < 0 || value > 255) return NMI_ERR_INVALID_ARGUMENT;
         ctx->phase_mask = (int)value;
         return NMI_OK;
     case NMI_OPT_XCD_TILING:

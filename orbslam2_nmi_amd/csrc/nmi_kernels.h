@@ -44,6 +44,7 @@ struct GridArgs {
     unsigned int seq;               // sequence number of this posting launch (its parity is posted with the winner)
     unsigned long long *score_post; // nmi_eval_pair: pinned host word that receives (score bits | seq << 32), or nullptr
     struct SplitSlab *slabs;        // split kernel: one hand-off slab per candidate (see nmi_split_kernel.hip)
+    unsigned long long *dbg_stamps; // tools only (NMI_OPT_STAMPS): [workgroup][8] wall_clock64 stamps at phase boundaries
     uint32_t *dbg_joint, *dbg_h1, *dbg_h2;
     float *dbg_sums;
     int hist_variant;             // 0 per-pixel wrap test, 1 batched, 2 unchecked (ablation), 3 optimistic + verify (default), 4 pipelined (experimental)

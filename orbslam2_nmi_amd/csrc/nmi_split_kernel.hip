@@ -39,9 +39,12 @@ constexpr int kMinLdsBytes = 84 * 1024;  // more than half of the CU's 160 KiB: 
 template <int K>
 struct SplitLds {
     static constexpr int kRows = kBins / K;
-    static constexpr int kUsed = (kRows * kBins + kBins + 4) * 4;
+    static constexpr int kUsed = (kRows * kBins + 4 * kBins + 4) * 4;
     uint32_t joint[kRows * kBins];  // [row = render intensity - part * kRows][frame intensity]; bank = frame intensity & 31
     uint32_t hist_warped[kBins];    // column sums over this part's rows
+    uint32_t fin_render[kBins];     // the last part's copy of the candidate's slab: render marginal,
+    uint32_t fin_warped[kBins];     //   frame marginal (sum of the K column partials),
+    float fin_rows[kBins];          //   joint row sums
     uint32_t is_last;
     uint32_t pad0[3];
     uint32_t pad[kUsed < kMinLdsBytes ? (kMinLdsBytes - kUsed) / 4 : 4];
@@ -63,30 +66,54 @@ __device__ __forceinline__ float load_sc1(const float *p)
 
 // 16 pixels of one lane, hot case (BG on, 256 bins).  xorpat holds (part * kRows) in every byte: after r ^= xorpat a pixel
 // belongs to this part iff its render byte is < kRows, and that byte is its local row.  One v_perm_b32 then builds the
-// 16-bit counter indices (row << 8 | frame intensity) of TWO pixels; index * 4 is the LDS byte address, and "address
-// inside the joint array" is the ownership test: per pixel 1/4 xor + 1/2 perm + 1 shift (SDWA word select) + 1 compare.
+// 16-bit counter indices (row << 8 | frame intensity) of TWO pixels; index * 4 is the LDS byte address (the joint array
+// sits at LDS address 0: it is the first member of the kernel's only __shared__ object; checked at kernel start), and
+// "address inside the joint array" is the ownership test.  A wavefront retires one instruction per ~5 cycles whatever
+// the other wavefronts do (tools/ubench/valu_rate.hip), so the loop is bound by its instruction count: the 23
+// instructions per 4 pixels are spelled out (hipcc's version of the same C++ had 39: duplicated xors, moves, nops and
+// waits between the predicated adds).  Per pixel: 1/4 xor + 1/2 perm + 1 SDWA shift + compare, then EXEC <- mask + ds_add.
 template <int K>
-__device__ __forceinline__ void add_chunk_split(uint32_t *joint, const uint4 &rv, const uint4 &wv, uint32_t xorpat)
+__device__ __forceinline__ void add_chunk_split(const uint4 &rv, const uint4 &wv, uint32_t xorpat)
 {
     constexpr uint32_t kLimit = (uint32_t)(kBins / K) * kBins * 4u;
-    char *const base = reinterpret_cast<char *>(joint);
-    const uint32_t r[4] = {rv.x ^ xorpat, rv.y ^ xorpat, rv.z ^ xorpat, rv.w ^ xorpat};
+    const uint32_t r[4] = {rv.x, rv.y, rv.z, rv.w};
     const uint32_t w[4] = {wv.x, wv.y, wv.z, wv.w};
-    const uint32_t two = 2;
+    const uint32_t two = 2, one = 1, sel01 = 0x05010400u, sel23 = 0x07030602u, limit = kLimit;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        // v_perm_b32: selector bytes 0-3 pick from the second operand (frame), 4-7 from the first (render)
-        const uint32_t k01 = __builtin_amdgcn_perm(r[q], w[q], 0x05010400u);  // (r0 << 8 | w0) | (r1 << 8 | w1) << 16
-        const uint32_t k23 = __builtin_amdgcn_perm(r[q], w[q], 0x07030602u);
-        uint32_t a0, a1, a2, a3;
-        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(a0) : "v"(two), "v"(k01));
-        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(a1) : "v"(two), "v"(k01));
-        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(a2) : "v"(two), "v"(k23));
-        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(a3) : "v"(two), "v"(k23));
-        if (__builtin_expect(a0 < kLimit, 1)) (void)__hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(base + a0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (__builtin_expect(a1 < kLimit, 1)) (void)__hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(base + a1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (__builtin_expect(a2 < kLimit, 1)) (void)__hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(base + a2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (__builtin_expect(a3 < kLimit, 1)) (void)__hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(base + a3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t t0, t1, t2, t3;
+        unsigned long long m0, m1, m2, m3, saved;
+        // v_perm_b32: selector bytes 0-3 pick from the second operand (frame), 4-7 from the first (render):
+        // t0 = (r0 << 8 | w0) | (r1 << 8 | w1) << 16, t1 the same for pixels 2, 3.
+        // The four ownership masks are formed first (VALU -> SGPR pairs, back to back), then EXEC is loaded with each in
+        // turn for its ds_add: one pixel at a time through compare -> s_and_saveexec -> ds_add -> restore costs ~90
+        // cycles of the wavefront per pixel in VALU <-> SALU <-> EXEC round trips (measured: 13 us per 640x480 pair).
+        asm volatile(
+            "v_xor_b32 %0, %10, %9\n\t"
+            "v_perm_b32 %1, %0, %11, %13\n\t"
+            "v_perm_b32 %0, %0, %11, %12\n\t"
+            "v_lshlrev_b32_sdwa %2, %14, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+            "v_lshlrev_b32_sdwa %3, %14, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+            "v_lshlrev_b32_sdwa %1, %14, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+            "v_lshlrev_b32_sdwa %0, %14, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+            "s_mov_b64 %8, exec\n\t"
+            "v_cmp_gt_u32_e64 %6, %16, %2\n\t"
+            "v_cmp_gt_u32_e64 %7, %16, %3\n\t"
+            "v_cmp_gt_u32_e64 %5, %16, %1\n\t"
+            "v_cmp_gt_u32_e64 %4, %16, %0\n\t"
+            "s_nop 0\n\t"
+            "s_mov_b64 exec, %6\n\t"
+            "ds_add_u32 %2, %15\n\t"
+            "s_mov_b64 exec, %7\n\t"
+            "ds_add_u32 %3, %15\n\t"
+            "s_mov_b64 exec, %5\n\t"
+            "ds_add_u32 %1, %15\n\t"
+            "s_mov_b64 exec, %4\n\t"
+            "ds_add_u32 %0, %15\n\t"
+            "s_mov_b64 exec, %8"
+            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(saved)
+            : "s"(xorpat), "v"(r[q]), "v"(w[q]), "s"(sel01), "s"(sel23), "v"(two), "v"(one), "s"(limit)
+            : "memory");
     }
 }
 
@@ -111,7 +138,7 @@ __device__ __forceinline__ void add_chunk_careful(uint32_t *joint, const uint4 &
     const bool flat = rv.x == rv.y && rv.y == rv.z && rv.z == rv.w && wv.x == wv.y && wv.y == wv.z && wv.z == wv.w &&
                       rv.x == rb * 0x01010101u && wv.x == wb * 0x01010101u;
     if (!__all(flat)) {
-        add_chunk_split<K>(joint, rv, wv, xorpat);
+        add_chunk_split<K>(rv, wv, xorpat);
         return;
     }
     const uint32_t key = (rb << 8) | wb;
@@ -145,35 +172,37 @@ __device__ __forceinline__ void histogram_split(uint32_t *joint, const GridArgs 
             return *reinterpret_cast<const uint4 *>(render + ((uint32_t)(__mul24(y, a.flip_row) + c + a.flip_base) << 4));
         };
         if (FAST) {
-            // Four named register sets: three chunk pairs (96 B per lane, 96 KiB per workgroup) are in flight while one is
-            // added -- a part has to pull the whole pair through one CU in a few microseconds.  Loads are unconditional
-            // (index clamped), only the adds are predicated.  A flat hint (first dword == last dword in both images for the
-            // whole wavefront) sends the wavefront to the careful loop for the rest of the candidate.
+            // Software pipeline with two named register sets of TWO chunk pairs each (64 B per lane and set): while one
+            // set's 32 pixels are added the other set's four loads are in flight -- a part has to pull the whole pair
+            // through one CU in a few microseconds, and one set of adds (~1400 cycles per SIMD) covers an L2 round trip.
+            // Loads are unconditional (index clamped), only the adds are predicated.  A flat hint (first dword == last
+            // dword in both images for the whole wavefront) sends the wavefront to the careful loop for the rest of the
+            // candidate.
             const uint32_t xorpat = (uint32_t)part * kRows * 0x01010101u;
-            const int iters = (nchunks + NT - 1) / NT;
+            const int iters = (nchunks + 2 * NT - 1) / (2 * NT);  // workgroup-uniform
             int resume = -1;
             int ch = tid;
-            uint4 w0 = ldw(ch), r0 = ldr(ch), w1 = ldw(ch + NT), r1 = ldr(ch + NT), w2 = ldw(ch + 2 * NT), r2 = ldr(ch + 2 * NT), w3, r3;
+            uint4 wa0 = ldw(ch), ra0 = ldr(ch), wa1 = ldw(ch + NT), ra1 = ldr(ch + NT), wb0, rb0, wb1, rb1;
             const bool fold = !(a.phase_mask & 4);
 #define NMI_SPLIT_STEP(RC, WC, OFF)                                          \
     if (fold && __builtin_expect(flat_hint(RC, WC), 0)) {                    \
         resume = ch + (OFF) * NT;                                            \
         break;                                                               \
     }                                                                        \
-    if (ch + (OFF) * NT < nchunks) add_chunk_split<K>(joint, RC, WC, xorpat);
-            for (int it = 0; it < iters; it += 4) {
-                w3 = ldw(ch + 3 * NT);
-                r3 = ldr(ch + 3 * NT);
-                NMI_SPLIT_STEP(r0, w0, 0)
-                w0 = ldw(ch + 4 * NT);
-                r0 = ldr(ch + 4 * NT);
-                NMI_SPLIT_STEP(r1, w1, 1)
-                w1 = ldw(ch + 5 * NT);
-                r1 = ldr(ch + 5 * NT);
-                NMI_SPLIT_STEP(r2, w2, 2)
-                w2 = ldw(ch + 6 * NT);
-                r2 = ldr(ch + 6 * NT);
-                NMI_SPLIT_STEP(r3, w3, 3)
+    if (ch + (OFF) * NT < nchunks) add_chunk_split<K>(RC, WC, xorpat);
+            for (int it = 0; it < iters; it += 2) {
+                wb0 = ldw(ch + 2 * NT);
+                rb0 = ldr(ch + 2 * NT);
+                wb1 = ldw(ch + 3 * NT);
+                rb1 = ldr(ch + 3 * NT);
+                NMI_SPLIT_STEP(ra0, wa0, 0)
+                NMI_SPLIT_STEP(ra1, wa1, 1)
+                wa0 = ldw(ch + 4 * NT);
+                ra0 = ldr(ch + 4 * NT);
+                wa1 = ldw(ch + 5 * NT);
+                ra1 = ldr(ch + 5 * NT);
+                NMI_SPLIT_STEP(rb0, wb0, 2)
+                NMI_SPLIT_STEP(rb1, wb1, 3)
                 ch += 4 * NT;
             }
 #undef NMI_SPLIT_STEP
@@ -278,55 +307,51 @@ __device__ __forceinline__ void decode_split(SplitLds<K> &lds, const GridArgs &a
     }
 }
 
-// The part that arrived last, wavefront 0: the three 256-element trees of AddVectorPairwiseKernel (NMI.cu:295-339) side
-// by side in DPP rows 0 (render marginal), 1 (frame marginal = sum of the K column partials), 2 (joint row sums), then
-// the score.  Every load of handed-off bytes is an sc1 load (they were sc1 stores of other workgroups).
+// The part that arrived last.  All wavefronts first fetch the candidate's slab (every load of handed-off bytes is an sc1
+// load: they were sc1 stores of other workgroups) in ONE round trip -- lane t sums the K column partials of bin t, others
+// take the render marginal and the row sums -- into LDS; then wavefront 0 runs the three 256-element trees of
+// AddVectorPairwiseKernel (NMI.cu:295-339) side by side in DPP rows 0 (render marginal), 1 (frame marginal), 2 (joint
+// row sums), and the score.  (Fetched by wavefront 0 alone, 16 + 16K dependent loads per lane, this took 12 us.)
 template <int K>
-__device__ __forceinline__ void final_split(const GridArgs &a, const SplitSlab *slab, int lane, int p, int w, int s,
+__device__ __forceinline__ void gather_slab(SplitLds<K> &lds, const SplitSlab *slab, int tid)
+{
+    if (tid < kBins) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) c += load_sc1(&slab->hw_part[j][tid]);
+        lds.fin_warped[tid] = c;
+    } else if (tid < 2 * kBins) {
+        lds.fin_render[tid - kBins] = load_sc1(&slab->hist_render[tid - kBins]);
+    } else if (tid < 3 * kBins) {
+        lds.fin_rows[tid - 2 * kBins] = load_sc1(&slab->row_sums[tid - 2 * kBins]);
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void final_split(const SplitLds<K> &lds, const GridArgs &a, int lane, int p, int w, int s,
                                             unsigned long long &prev_key)
 {
     const int i = lane & 15, r = lane >> 4;
-    uint32_t cl[8], ch[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) cl[k] = ch[k] = 0;
-    if (r == 0) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            cl[k] = load_sc1(&slab->hist_render[i + 16 * k]);
-            ch[k] = load_sc1(&slab->hist_render[i + 16 * k + 128]);
-        }
-    } else if (r == 1) {
-#pragma unroll
-        for (int j = 0; j < K; ++j)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                cl[k] += load_sc1(&slab->hw_part[j][i + 16 * k]);
-                ch[k] += load_sc1(&slab->hw_part[j][i + 16 * k + 128]);
-            }
-    }
+    const uint32_t *h = r == 0 ? lds.fin_render : lds.fin_warped;
     float lo[8], hi[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        lo[k] = a.table[cl[k]];  // rows 2, 3 fetch table[0] = 0
-        hi[k] = a.table[ch[k]];
+        lo[k] = a.table[r < 2 ? h[i + 16 * k] : 0u];  // rows 2, 3 fetch table[0] = 0
+        hi[k] = a.table[r < 2 ? h[i + 16 * k + 128] : 0u];
     }
     if (r == 2) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            lo[k] = load_sc1(&slab->row_sums[i + 16 * k]);
-            hi[k] = load_sc1(&slab->row_sums[i + 16 * k + 128]);
+            lo[k] = lds.fin_rows[i + 16 * k];
+            hi[k] = lds.fin_rows[i + 16 * k + 128];
         }
     }
     const float x = row_tree_16(lane_tree_16(lo, hi));
     const float a1 = __shfl(x, 0, 64), a2 = __shfl(x, 16, 64), a3 = __shfl(x, 32, 64);
     if (a.dbg_h1 || a.dbg_h2) {
         for (int t = lane; t < kBins; t += 64) {
-            if (a.dbg_h1) a.dbg_h1[t] = load_sc1(&slab->hist_render[t]);
-            if (a.dbg_h2) {
-                uint32_t c = 0;
-                for (int j = 0; j < K; ++j) c += load_sc1(&slab->hw_part[j][t]);
-                a.dbg_h2[t] = c;
-            }
+            if (a.dbg_h1) a.dbg_h1[t] = lds.fin_render[t];
+            if (a.dbg_h2) a.dbg_h2[t] = lds.fin_warped[t];
         }
     }
     if (lane == 0) commit_score(a, p, w, s, a1, a2, a3, prev_key);
@@ -345,6 +370,11 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_split_kernel(GridArgs a
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
+    auto stamp = [&](int k) {  // tools/small_grid_time.py --stamps: where a part's time goes (100 MHz clock)
+        if (a.dbg_stamps && tid == 0) a.dbg_stamps[blockIdx.x * 8 + k] = wall_clock64();
+    };
+    stamp(0);
+    const long long clk0 = a.dbg_stamps ? clock64() : 0;  // shader-clock counter: with the wall-clock stamps it gives the clock held
     if (blockIdx.x == 0 && tid == 0 && a.reset_key) *a.reset_key = 0ull;  // next launch's slot; idle during this one
     {
         uint4 *j4 = reinterpret_cast<uint4 *>(lds.joint);
@@ -352,6 +382,8 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_split_kernel(GridArgs a
         for (int k = tid; k < SplitLds<K>::kRows * kBins / 4; k += kBlock) j4[k] = z;
     }
     if (tid < kBins) lds.hist_warped[tid] = 0;
+    // add_chunk_split addresses the counters from LDS address 0
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds.joint != 0u) __builtin_trap();
     __syncthreads();
 
     const int total = a.S_local * a.Wn;
@@ -364,12 +396,15 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_split_kernel(GridArgs a
         const int w = p / a.S_local, s = p - w * a.S_local;
         SplitSlab *slab = a.slabs + p;
 
+        stamp(1);
         if (a.phase_mask & 1)
             histogram_split<K, FAST>(lds.joint, a, a.render_stack + (size_t)s * a.npix, a.warp_stack + (size_t)w * a.npix, tid, part,
                                      use_bg != 0);
         __syncthreads();
+        stamp(2);
         decode_split<K>(lds, a, slab, part, wave, lane);
         __syncthreads();
+        stamp(3);
         if (tid < kBins) {
             store_sc1(&slab->hw_part[part][tid], lds.hist_warped[tid]);
             lds.hist_warped[tid] = 0;
@@ -383,11 +418,22 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_split_kernel(GridArgs a
             lds.is_last = last ? 1u : 0u;
         }
         __syncthreads();
-        if (lds.is_last && wave == 0) final_split<K>(a, slab, lane, p, w, s, prev_key);
-        // wavefront 0 writes is_last again only after this final phase (tid 0 is one of its lanes); the other wavefronts
-        // meanwhile touch only the (already cleared) counters of the next unit.
+        stamp(4);
+        if (lds.is_last) {  // workgroup-uniform
+            gather_slab<K>(lds, slab, tid);
+            __syncthreads();
+            if (wave == 0) {
+                final_split<K>(lds, a, lane, p, w, s, prev_key);
+                stamp(5);
+            }
+            // wavefront 0 writes is_last / fin_* again only after this final phase (tid 0 is one of its lanes, and the next
+            // unit's gather sits behind four more barriers); the other wavefronts meanwhile touch only the (already
+            // cleared) counters of the next unit.
+        }
     }
     if (tid == 0 && !(a.phase_mask & 16)) publish_winner(a, prev_key);
+    stamp(6);
+    if (a.dbg_stamps && tid == 0) a.dbg_stamps[blockIdx.x * 8 + 7] = (unsigned long long)(clock64() - clk0);
 }
 
 int split_workgroups(int candidates, int parts) { return ((candidates + 7) / 8) * 8 * parts; }
