@@ -73,20 +73,85 @@ def load_pmc_traffic():
         return None
 
 
+def init_dist(args):
+    """(rank, local_rank, world, dist or None).  One process per GPU, launched by torch.distributed.run for N > 1."""
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (no CPU fallback for the NMI path)")
+    if args.all_on_device0:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1 or args.force_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    return rank, local_rank, world, dist
+
+
+def timed_region(fn, dist):
+    """barrier + synchronize on both sides of fn(); returns (MAX over ranks of the elapsed seconds, fn's result)."""
+    import torch
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync_all()
+    t0 = time.perf_counter()
+    out = fn()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, out
+
+
+def load_pmc_lds():
+    """LDS-side counters of the dominant kernel from the committed PMC profile (profiles/pmc_lds.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_lds.json")) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    return {k: d.get(k) for k in ("lds_wave_instructions_per_launch", "lds_idx_active_cycles_per_launch", "conflict_ratio",
+                                  "lds_active_cycles_per_wave_instruction", "conflict_free_cycles_per_wave_instruction", "source")}
+
+
 def run_stream_config(args):
-    """BASELINE.json config 5 on the local GPU: 100-keyframe synthetic sequence, 3 search levels per keyframe (steps halved
-    per level like NmiSearchKernel::resizeKernel), 3^6 candidates per level at 848x480, render stacks streamed from pinned
-    host memory through the double-buffered pipeline (nmi_stream_*), warp stacks produced on the device per level.
+    """BASELINE.json configs[4]: 100-keyframe synthetic sequence, 3 search levels per keyframe (steps halved per level like
+    NmiSearchKernel::resizeKernel), 3^6 candidates per level at 848x480, render stacks streamed from pinned host memory
+    through the double-buffered pipeline (nmi_stream_*), warp stacks produced on the device per level.
+    N ranks: the keyframes of the sequence are dealt round-robin (sharding.keyframe_share: replicas, no collective on the
+    data path -- the levels of one keyframe are sequential in the reference, Tracking.cc:2088-2130, keyframes are not);
+    every rank streams its own share through its own pipeline and the per-level winners are gathered with one all-reduce
+    at the end, inside the timed region.  Total work is fixed (--keyframes): "scaling": "strong".
     Not the headline line: prints its own JSON (keyframes/s and evals/s, H2D included)."""
     import torch
 
     import orbslam2_nmi_amd as nmi
-    from orbslam2_nmi_amd import capi, synthetic as sy
+    from orbslam2_nmi_amd import capi, sharding, synthetic as sy
 
+    rank, local_rank, world, dist = init_dist(args)
     w, h, counts, levels, pool = 848, 480, (3, 3, 3), 3, 4
     K = sy.intrinsics(w, h)
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    frames, stacks, homs, planted = [], [], [], []
+    frames, stacks, homs = [], [], []
     for kf in range(pool):
         B = sy.scene(w, h, 9000 + kf)
         frames.append(torch.from_numpy(sy.camera_frame(B, 9500 + kf)).pin_memory())
@@ -96,49 +161,62 @@ def run_stream_config(args):
     ctx = nmi.NmiContext(w, h, render_bottom_up=False)
     st = nmi.NmiStream(ctx, 27, 27, depth=2)
     n_kf = args.keyframes
+    red_dev = "cuda" if (dist is not None and dist.get_backend() == "nccl") else "cpu"
 
     def run(nk):
-        pending, winners = [], []
-        for i in range(nk * levels):
-            kf, lvl = (i // levels) % pool, i % levels
-            pending.append(st.submit(stacks[kf * levels + lvl], frames[kf], homs[kf * levels + lvl]))
-            if len(pending) == 2:
-                winners.append(st.wait(pending.pop(0)))
-        while pending:
-            winners.append(st.wait(pending.pop(0)))
-        return winners
+        table = sharding.new_keyframe_table(nk, levels)
+        pending = []
 
-    run(4)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    winners = run(n_kf)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+        def collect():
+            kf, lvl, t = pending.pop(0)
+            idx, sc = st.wait(t)
+            sharding.store_keyframe_result(table, kf, lvl, idx, sc)
+
+        for kf in sharding.keyframe_share(nk, rank, world):
+            for lvl in range(levels):
+                p = kf % pool
+                pending.append((kf, lvl, st.submit(stacks[p * levels + lvl], frames[p], homs[p * levels + lvl])))
+                if len(pending) == 2:
+                    collect()
+        while pending:
+            collect()
+        return sharding.gather_keyframe_table(table, world, dist, red_dev)
+
+    run(4 * world)
+    dt, table = timed_region(lambda: run(n_kf), dist)
     centre = 13 * 27 + 13
-    if any(wn[0] != centre for wn in winners):
-        sys.exit(f"stream config: unexpected winners {sorted(set(x[0] for x in winners))}")
-    evals = n_kf * levels * 729
-    h2d = n_kf * levels * (27 + 1) * w * h
-    print(json.dumps({"metric": "keyframes/s (config 5: 848x480, 3 levels x 729 candidates, render stacks streamed H2D)",
-                      "value": n_kf / dt, "unit": "keyframes/s", "evals_per_s": evals / dt, "n_gpus": 1,
-                      "keyframes": n_kf, "levels": levels, "h2d_GBps": h2d / dt / 1e9, "data": "synthetic",
-                      "config": {"workload": "BASELINE.json configs[4] on one GPU", "width": w, "height": h,
-                                 "pipeline_depth": 2}}))
+    if not (table[..., 0] == centre).all():
+        sys.exit(f"rank {rank}: stream config: unexpected winners {sorted(set(table[..., 0].reshape(-1).tolist()))}")
+    if rank == 0:
+        evals = n_kf * levels * 729
+        h2d = n_kf * levels * (27 + 1) * w * h
+        print(json.dumps({"metric": "keyframes/s (BASELINE configs[4]: 848x480, 3 levels x 729 candidates, render stacks streamed H2D)",
+                          "value": n_kf / dt, "unit": "keyframes/s", "evals_per_s": evals / dt, "n_gpus": world,
+                          "keyframes": n_kf, "levels": levels, "h2d_GBps_all_ranks": h2d / dt / 1e9, "data": "synthetic",
+                          "higher_is_better": True, "scaling": "strong",
+                          "config": {"workload": "BASELINE.json configs[4]: 100-keyframe sequence, coarse-to-fine 3 levels, double-buffered render stacks",
+                                     "width": w, "height": h, "pipeline_depth": 2,
+                                     "parallelism": "replicas: keyframes dealt round-robin to ranks, winners gathered by one all-reduce"
+                                     if world > 1 else "one rank"}}))
     st.close()
     ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def run_e2e_config(args):
     """Everything on the device: coloured point cloud + camera frame in HBM; per keyframe 3 search levels, each level =
     27 renders of the cloud (nmi_render_points) + 27 warps of the frame (nmi_warp_stack) + the 729-candidate search.
-    Only matrices cross PCIe.  Not the headline line (the render / warp producers are the section-8f rows)."""
+    Only matrices cross PCIe.  N ranks: keyframes dealt round-robin like --config stream (every rank holds the cloud).
+    Not the headline line (the render / warp producers are the section-8f rows)."""
     import torch
 
     import orbslam2_nmi_amd as nmi
-    from orbslam2_nmi_amd import capi, hostapi as H, synthetic as sy
+    from orbslam2_nmi_amd import capi, hostapi as H, sharding, synthetic as sy
 
+    rank, local_rank, world, dist = init_dist(args)
     w, h, levels = 848, 480, 3
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     K = sy.intrinsics(w, h)
     rp = capi.RenderParams(fx=K[0, 0], fy=K[1, 1], cx=K[0, 2], cy=K[1, 2], near_plane=5.0, far_plane=30.0, point_size=3.0)
     # a textured plane at 10 m, ~1.3 M points (about 2 per pixel of the view), plus the frame seen from a displaced pose
@@ -170,36 +248,41 @@ def run_e2e_config(args):
     level = nmi.NmiLevel(ctx, dx, dr, frame, 27, 27, 3.0) if not args.no_graph else None
 
     def keyframe():
-        out = None
+        out = []
         for l in range(levels):
             if level is not None:  # one hipGraphLaunch per level
-                out = level.run(mvps[l], homs[l])
+                out.append(level.run(mvps[l], homs[l]))
             else:                  # the same seven operations enqueued one by one
                 ctx.render_points(dx, dr, mvps[l], 3.0, out=rs, sync=False)
                 ctx.warp_stack(frame, homs[l], out=ws, sync=False)
-                out = ctx.search_grid(rs, ws)
+                out.append(ctx.search_grid(rs, ws))
         return out
 
     for _ in range(3):
         res = keyframe()
     # the frame was taken at the grid centre: at the coarse level the centre cell must win outright (at the finest level
     # neighbouring cells differ by sub-pixel shifts and pixel-snapped sprites plus camera noise decide between them)
-    coarse = level.run(mvps[0], homs[0]) if level is not None else None
-    if coarse is not None and coarse[0] != 13 * 27 + 13:
-        sys.exit(f"e2e config: unexpected coarse-level winner {coarse}")
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.keyframes):
-        keyframe()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    print(json.dumps({"metric": "keyframes/s (device end to end: 848x480, 3 levels x (27 cloud renders + 27 warps + 729-candidate search))",
-                      "value": args.keyframes / dt, "unit": "keyframes/s", "evals_per_s": args.keyframes * levels * 729 / dt,
-                      "n_gpus": 1, "points": int(xyz.shape[0]), "data": "synthetic", "ms_per_level": dt / args.keyframes / levels * 1e3,
-                      "hip_graph": level is not None}))
+    if res[0][0] != 13 * 27 + 13:
+        sys.exit(f"rank {rank}: e2e config: unexpected coarse-level winner {res[0]}")
+    red_dev = "cuda" if (dist is not None and dist.get_backend() == "nccl") else "cpu"
+    n_kf = args.keyframes
+    dt, table = timed_region(lambda: sharding.run_keyframes(n_kf, levels, rank, world, lambda kf: keyframe(), dist, red_dev), dist)
+    if not (table[:, 0, 0] == 13 * 27 + 13).all():
+        sys.exit(f"rank {rank}: e2e config: a coarse level lost the centre cell")
+    if rank == 0:
+        print(json.dumps({"metric": "keyframes/s (device end to end: 848x480, 3 levels x (27 cloud renders + 27 warps + 729-candidate search))",
+                          "value": n_kf / dt, "unit": "keyframes/s", "evals_per_s": n_kf * levels * 729 / dt,
+                          "n_gpus": world, "points": int(xyz.shape[0]), "data": "synthetic",
+                          "ms_per_level_per_rank": dt / n_kf / levels * 1e3 * world,
+                          "hip_graph": level is not None, "higher_is_better": True, "scaling": "strong",
+                          "config": {"workload": "BASELINE.json configs[4] shape with the render / warp producers on the device",
+                                     "parallelism": "replicas: keyframes dealt round-robin to ranks" if world > 1 else "one rank"}}))
     if level is not None:
         level.close()
     ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -245,28 +328,8 @@ def main():
     import orbslam2_nmi_amd as nmi
     from orbslam2_nmi_amd import synthetic as sy
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
-        args.gpus = world
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a HIP device (no CPU fallback for the NMI path)")
+    rank, local_rank, world, dist = init_dist(args)
     nmi.load_library()
-    if args.all_on_device0:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or args.force_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_PORT", "29577")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     # ---- synthetic inputs, resident in HBM before any timing ------------------------------------------
     # rank 0 holds the renders of the planted scene; other ranks render a different scene (their candidates score
@@ -412,8 +475,12 @@ def main():
         per_launch_evals = S_PER_RANK * WN
         achieved = per_launch_evals * algorithmic_bytes_per_eval(WIDTH, HEIGHT) / (kernel_ms * 1e-3) / 1e9
         out = {
-            "metric": f"pose-candidate NMI evals/sec ({WIDTH}x{HEIGHT}, 256 bins)",
+            "metric": f"pose-candidate NMI evals/sec ({WIDTH}x{HEIGHT}, 256 bins)" +
+                      (", one blocking nmi_search_grid call per step (SURVEY.md 8d)" if args.blocking else
+                       ", throughput mode: steps enqueued back to back, every winner read back and checked in the timed region"),
             "value": evals_per_step * args.steps / elapsed,
+            # SURVEY.md 8(d) defines the metric on ONE blocking nmi_search_grid call including its 8-byte read-back:
+            "blocking_call_evals_per_s": per_launch_evals / (blocking_call_ms * 1e-3),
             "unit": "evals/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -436,6 +503,9 @@ def main():
                         f"MAX all-reduce (RCCL) of the 8-byte winners, {bucket} steps per message")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_pmc_traffic() if args.config == "c2" else None,
+                         "lds": load_pmc_lds() if args.config == "c2" else None,
+                         "note": "frac is the contract's ALGORITHMIC fraction (2*W*H+4 bytes per evaluation / kernel time / 8 TB/s); "
+                                 "the inputs live in L2 / Infinity Cache (traffic) and the kernel is bound by LDS atomic issue, see lds",
                          "kernel": "nmi_grid_kernel", "kernel_ms": kernel_ms, "kernel_ms_exclusive": kernel_ms_exclusive,
                          "algorithmic_bytes_per_launch": per_launch_evals * algorithmic_bytes_per_eval(WIDTH, HEIGHT)},
         }

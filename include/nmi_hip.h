@@ -209,6 +209,10 @@ int nmi_level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int64
 int nmi_level_create_mesh(nmi_ctx *ctx, const float *d_xyz, const float *d_uv, int64_t n_triangles, const nmi_texture *tex,
                           const uint8_t *d_frame, int32_t S, int32_t Wn, nmi_level **out);
 int nmi_level_run(nmi_level *lv, const float *h_mvps, const double *h_forward, int64_t *h_best_index, float *h_best_score);
+/* Host copies of what the latest nmi_level_run produced: the S renders [S][H][W], the Wn warps [Wn][H][W] and the rating
+ * table [Wn][S] (any pointer may be NULL).  Blocking; for tests and debugging (the reference's orb_prop_log dumps,
+ * src/Tracking.cc:1911-1948, serve the same purpose). */
+int nmi_level_copy_outputs(nmi_level *lv, uint8_t *h_renders, uint8_t *h_warps, float *h_ratings);
 int nmi_level_destroy(nmi_level *lv);
 
 /*
@@ -228,6 +232,11 @@ int nmi_stream_destroy(nmi_stream *st);
 int nmi_stream_submit(nmi_stream *st, const uint8_t *h_render_stack, int32_t S, const uint8_t *h_frame,
                       const double *h_forward, int32_t Wn, int64_t *ticket);
 int nmi_stream_wait(nmi_stream *st, int64_t ticket, int64_t *h_best_index, float *h_best_score);
+/* Optional rating tables: after nmi_stream_keep_ratings(st, 1) every submission also stores its [Wn][S] table in its slot;
+ * nmi_stream_copy_ratings copies the table of a ticket that has been waited for (n = Wn * S floats), valid until the
+ * slot is submitted to again. */
+int nmi_stream_keep_ratings(nmi_stream *st, int32_t enabled);
+int nmi_stream_copy_ratings(nmi_stream *st, int64_t ticket, float *h_ratings, int64_t n);
 
 /* Packed-key helpers (host side, pure). */
 uint64_t nmi_key_pack(float score, int64_t global_linear_index);

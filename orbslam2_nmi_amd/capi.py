@@ -23,9 +23,9 @@ ERR_NOT_READY = -4
 # Every symbol include/nmi_hip.h declares; tests check that the library exports all of them.
 EXPORTED_SYMBOLS = (
     "nmi_params_default", "nmi_create", "nmi_destroy", "nmi_set_stream", "nmi_synchronize", "nmi_eval_pair", "nmi_eval_pair_debug",
-    "nmi_search_grid", "nmi_search_grid_shard", "nmi_search_grid_block", "nmi_warp_homographies", "nmi_warp_stack", "nmi_render_mvp", "nmi_render_points", "nmi_level_create", "nmi_level_create_mesh", "nmi_level_run", "nmi_level_destroy", "nmi_texture_create",
+    "nmi_search_grid", "nmi_search_grid_shard", "nmi_search_grid_block", "nmi_warp_homographies", "nmi_warp_stack", "nmi_render_mvp", "nmi_render_points", "nmi_level_create", "nmi_level_create_mesh", "nmi_level_run", "nmi_level_copy_outputs", "nmi_level_destroy", "nmi_texture_create",
     "nmi_texture_destroy", "nmi_render_mesh", "nmi_stream_create", "nmi_stream_destroy",
-    "nmi_stream_submit", "nmi_stream_wait", "nmi_key_pack", "nmi_key_unpack", "nmi_search_grid_rccl", "nmi_search_grid_block_rccl",
+    "nmi_stream_submit", "nmi_stream_wait", "nmi_stream_keep_ratings", "nmi_stream_copy_ratings", "nmi_key_pack", "nmi_key_unpack", "nmi_search_grid_rccl", "nmi_search_grid_block_rccl",
     "nmi_rccl_unique_id", "nmi_rccl_comm_init", "nmi_rccl_comm_destroy", "nmi_set_profiling", "nmi_last_kernel_ms",
     "nmi_set_option", "nmi_copy_term_table", "nmi_abi_version", "nmi_error_string", "nmi_last_error_detail", "nmi_get_info",
 )
@@ -90,11 +90,14 @@ def load_library(build_if_missing=False):
     lib.nmi_level_create.argtypes = [vp, vp, vp, C.c_int64, vp, i32, i32, C.c_float, C.POINTER(vp)]
     lib.nmi_level_create_mesh.argtypes = [vp, vp, vp, C.c_int64, vp, vp, i32, i32, C.POINTER(vp)]
     lib.nmi_level_run.argtypes = [vp, f32p, C.POINTER(C.c_double), i64p, f32p]
+    lib.nmi_level_copy_outputs.argtypes = [vp, vp, vp, vp]
     lib.nmi_level_destroy.argtypes = [vp]
     lib.nmi_stream_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
     lib.nmi_stream_destroy.argtypes = [vp]
     lib.nmi_stream_submit.argtypes = [vp, vp, i32, vp, C.POINTER(C.c_double), i32, i64p]
     lib.nmi_stream_wait.argtypes = [vp, C.c_int64, i64p, f32p]
+    lib.nmi_stream_keep_ratings.argtypes = [vp, i32]
+    lib.nmi_stream_copy_ratings.argtypes = [vp, C.c_int64, f32p, C.c_int64]
     lib.nmi_key_pack.argtypes = [C.c_float, C.c_int64]
     lib.nmi_key_pack.restype = C.c_uint64
     lib.nmi_key_unpack.argtypes = [C.c_uint64, i64p, f32p]
@@ -476,6 +479,15 @@ class NmiLevel:
                         "nmi_level_run")
         return int(idx.value), np.float32(sc.value)
 
+    def outputs(self):
+        """-> (renders [S,H,W] u8, warps [Wn,H,W] u8, ratings [Wn,S] f32) of the latest run, as numpy (host copies)."""
+        h, w = self.ctx.height, self.ctx.width
+        r = np.empty((self.S, h, w), np.uint8)
+        v = np.empty((self.Wn, h, w), np.uint8)
+        t = np.empty((self.Wn, self.S), np.float32)
+        self.ctx._check(self._lib.nmi_level_copy_outputs(self._h, r.ctypes.data, v.ctypes.data, t.ctypes.data), "nmi_level_copy_outputs")
+        return r, v, t
+
     def close(self):
         if self._h and self._h.value:
             self._lib.nmi_level_destroy(self._h)
@@ -513,6 +525,16 @@ class NmiStream:
                         "nmi_stream_submit")
         self._keep[t.value] = (rs, frame_host, m)  # keep host buffers alive until the ticket completes
         return int(t.value)
+
+    def keep_ratings(self, on=True):
+        self.ctx._check(self._lib.nmi_stream_keep_ratings(self._h, int(bool(on))), "nmi_stream_keep_ratings")
+
+    def ratings(self, ticket, Wn, S):
+        """Rating table [Wn, S] of a ticket that has been waited for (needs keep_ratings())."""
+        t = np.empty((Wn, S), np.float32)
+        self.ctx._check(self._lib.nmi_stream_copy_ratings(self._h, int(ticket), t.ctypes.data_as(C.POINTER(C.c_float)), t.size),
+                        "nmi_stream_copy_ratings")
+        return t
 
     def wait(self, ticket):
         idx, sc = C.c_int64(0), C.c_float(0)

@@ -24,6 +24,7 @@ struct nmi_level {
     uint32_t *d_zbuf = nullptr;
     float *d_mvps = nullptr, *h_mvps = nullptr, *d_coeffs = nullptr, *h_coeffs = nullptr;
     int *d_order = nullptr;
+    float *d_ratings = nullptr;                 // [Wn][S] rating table of the latest replay
     unsigned long long *d_key = nullptr, *h_key = nullptr;
     unsigned int *d_done = nullptr;
     hipStream_t side = nullptr;                 // forked capture branch (warp)
@@ -41,7 +42,7 @@ int nmi_level_destroy(nmi_level *lv)
     (void)hipStreamSynchronize(lv->ctx->stream);
     if (lv->exec) (void)hipGraphExecDestroy(lv->exec);
     if (lv->graph) (void)hipGraphDestroy(lv->graph);
-    void *dev[] = {lv->d_renders, lv->d_warps, lv->d_zbuf, lv->d_mvps, lv->d_coeffs, lv->d_order, lv->d_key, lv->d_done};
+    void *dev[] = {lv->d_renders, lv->d_warps, lv->d_zbuf, lv->d_mvps, lv->d_coeffs, lv->d_order, lv->d_key, lv->d_done, lv->d_ratings};
     for (void *q : dev)
         if (q) (void)hipFree(q);
     void *host[] = {lv->h_mvps, lv->h_coeffs, lv->h_key};
@@ -94,6 +95,7 @@ static int level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_attr, i
     ok(hipMalloc((void **)&lv->d_mvps, (size_t)S * 16 * sizeof(float)));
     ok(hipMalloc((void **)&lv->d_coeffs, (size_t)Wn * 9 * sizeof(float)));
     ok(hipMalloc((void **)&lv->d_order, (size_t)total * sizeof(int)));
+    ok(hipMalloc((void **)&lv->d_ratings, (size_t)total * sizeof(float)));
     ok(hipMalloc((void **)&lv->d_key, sizeof(unsigned long long)));
     ok(hipMalloc((void **)&lv->d_done, sizeof(unsigned int)));
     // pinned, device-mapped, fine-grained: the prep kernel reads the parameters and the search kernel posts the winner
@@ -129,6 +131,7 @@ static int level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_attr, i
     a.mode = p.mode;
     a.table = ctx->table;
     a.order = lv->d_order;
+    a.ratings = lv->d_ratings;  // 4 bytes per candidate: kept so that a level can be checked against an oracle (nmi_level_copy_outputs)
     a.key = lv->d_key;        // reset by the prep node before every replay (the ping-pong of plain launches needs
     a.reset_key = nullptr;    // alternating arguments, which a replayed graph does not have)
     a.done = lv->d_done;
@@ -229,6 +232,19 @@ int nmi_level_run(nmi_level *lv, const float *h_mvps, const double *h_forward, i
     return nmi_key_unpack(key, h_best_index, h_best_score);
 }
 
+int nmi_level_copy_outputs(nmi_level *lv, uint8_t *h_renders, uint8_t *h_warps, float *h_ratings)
+{
+    if (!lv) return NMI_ERR_INVALID_ARGUMENT;
+    nmi_ctx *ctx = lv->ctx;
+    DeviceGuard guard(ctx->device);
+    NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // nmi_level_run returns when the winner is posted, a little before the graph has drained
+    const size_t npix = (size_t)ctx->npix;
+    if (h_renders) NMI_HIP_TRY(ctx, hipMemcpy(h_renders, lv->d_renders, npix * lv->S, hipMemcpyDeviceToHost));
+    if (h_warps) NMI_HIP_TRY(ctx, hipMemcpy(h_warps, lv->d_warps, npix * lv->Wn, hipMemcpyDeviceToHost));
+    if (h_ratings) NMI_HIP_TRY(ctx, hipMemcpy(h_ratings, lv->d_ratings, (size_t)lv->S * lv->Wn * sizeof(float), hipMemcpyDeviceToHost));
+    return NMI_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Streaming pipeline (config 5): double-buffered render stacks, copy stream beside the compute stream.
 // ---------------------------------------------------------------------------------------------------------
@@ -240,6 +256,8 @@ struct nmi_stream {
     hipStream_t copy = nullptr;
     struct Slot {
         uint8_t *d_renders = nullptr;
+        float *d_ratings = nullptr;  // [max_Wn][max_S], only with nmi_stream_keep_ratings
+        int S = 0, Wn = 0;           // grid of the slot's latest submission
         unsigned long long *d_key = nullptr;
         unsigned long long *h_key = nullptr;
         hipEvent_t copied = nullptr, done = nullptr;
@@ -253,6 +271,7 @@ struct nmi_stream {
     int warp_buf = 0;      // buffer holding the current warp stack
     int cur_Wn = 0;
     bool have_warps = false;
+    bool keep_ratings = false;
     int64_t next_ticket = 0;
 };
 
@@ -267,6 +286,7 @@ int nmi_stream_destroy(nmi_stream *st)
     for (int i = 0; st->slots && i < st->depth; ++i) {
         nmi_stream::Slot &s = st->slots[i];
         if (s.d_renders) (void)hipFree(s.d_renders);
+        if (s.d_ratings) (void)hipFree(s.d_ratings);
         if (s.d_key) (void)hipFree(s.d_key);
         if (s.h_key) (void)hipHostFree(s.h_key);
         if (s.copied) (void)hipEventDestroy(s.copied);
@@ -360,8 +380,12 @@ int nmi_stream_submit(nmi_stream *st, const uint8_t *h_render_stack, int32_t S, 
 
     // compute stream: search on the slot, winner to pinned host memory
     NMI_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s.copied, 0));
-    int rc = enqueue_grid(ctx, s.d_renders, S, 0, S, st->d_warps[st->warp_buf], st->cur_Wn, nullptr, s.d_key, false, nullptr,
-                          nullptr, nullptr, nullptr);
+    if (st->keep_ratings && !s.d_ratings)
+        NMI_HIP_TRY(ctx, hipMalloc((void **)&s.d_ratings, (size_t)st->max_S * st->max_Wn * sizeof(float)));
+    s.S = S;
+    s.Wn = st->cur_Wn;
+    int rc = enqueue_grid(ctx, s.d_renders, S, 0, S, st->d_warps[st->warp_buf], st->cur_Wn, st->keep_ratings ? s.d_ratings : nullptr,
+                          s.d_key, false, nullptr, nullptr, nullptr, nullptr);
     if (rc != NMI_OK) return rc;
     NMI_HIP_TRY(ctx, hipMemcpyAsync(s.h_key, s.d_key, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     NMI_HIP_TRY(ctx, hipEventRecord(s.done, ctx->stream));
@@ -369,6 +393,25 @@ int nmi_stream_submit(nmi_stream *st, const uint8_t *h_render_stack, int32_t S, 
     s.waited = false;
     *ticket = t;
     ++st->next_ticket;
+    return NMI_OK;
+}
+
+int nmi_stream_keep_ratings(nmi_stream *st, int32_t enabled)
+{
+    if (!st) return NMI_ERR_INVALID_ARGUMENT;
+    st->keep_ratings = enabled != 0;
+    return NMI_OK;
+}
+
+int nmi_stream_copy_ratings(nmi_stream *st, int64_t ticket, float *h_ratings, int64_t n)
+{
+    if (!st || !h_ratings || ticket < 0 || ticket >= st->next_ticket) return NMI_ERR_INVALID_ARGUMENT;
+    nmi_stream::Slot &s = st->slots[ticket % st->depth];
+    // valid from nmi_stream_wait(ticket) until the slot is submitted to again
+    if (s.ticket != ticket || !s.waited || !s.d_ratings || n != (int64_t)s.S * s.Wn) return NMI_ERR_INVALID_ARGUMENT;
+    nmi_ctx *ctx = st->ctx;
+    DeviceGuard guard(ctx->device);
+    NMI_HIP_TRY(ctx, hipMemcpy(h_ratings, s.d_ratings, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     return NMI_OK;
 }
 

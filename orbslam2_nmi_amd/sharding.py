@@ -66,3 +66,59 @@ def local_key_from_ratings(ratings_local, s_offset, s_total, w_offset=0):
             k = capi.key_pack(float(r[w, s]), global_index(w_offset + w, s_offset + s, s_total))
             best = max(best, k)
     return best
+
+
+# ---- keyframe streams (BASELINE.json configs[4]) -------------------------------------------------------------------------
+# The streamed loop (src/Tracking.cc:2088-2130: <= 4 coarse-to-fine levels per keyframe) is sequential inside a keyframe
+# -- level i+1 is centred on level i's winner -- but keyframes of a recorded sequence are independent searches.  With N
+# ranks the keyframes are dealt round-robin: rank r takes keyframes r, r + N, ...  ("replicas": no collective on the data
+# path; every rank holds the map and streams its own frames and render stacks).  Only the tiny per-keyframe results are
+# gathered at the end, in keyframe order.
+
+def keyframe_share(n_keyframes, rank, world):
+    """Keyframes of rank `rank`: r, r + world, r + 2 world, ..."""
+    if not (0 <= rank < world) or n_keyframes < 0:
+        raise ValueError("bad keyframe share request")
+    return list(range(rank, n_keyframes, world))
+
+
+def new_keyframe_table(n_keyframes, levels):
+    """Result table [n_keyframes, levels, 2] = (best index + 1, float32 score bits), zero = not computed on this rank."""
+    return np.zeros((n_keyframes, levels, 2), np.int64)
+
+
+def store_keyframe_result(table, kf, lvl, best_index, best_score):
+    table[kf, lvl, 0] = int(best_index) + 1  # -1 ("no candidate") -> 0
+    table[kf, lvl, 1] = int(np.float32(best_score).view(np.uint32))
+
+
+def gather_keyframe_table(table, world, dist=None, device="cpu", group=None):
+    """One SUM all-reduce of the result table (each row is written by exactly one rank) -> the complete table on every
+    rank, indices back in their -1-based form."""
+    import torch
+    if dist is not None and world > 1:
+        t = torch.from_numpy(table).to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        table = t.cpu().numpy()
+    table = table.copy()
+    table[..., 0] -= 1
+    return table
+
+
+def run_keyframes(n_keyframes, levels, rank, world, process_keyframe, dist=None, device="cpu", group=None):
+    """Every rank runs process_keyframe(kf) -> [(best_index, best_score)] * levels on its share; the results of all
+    keyframes come back on every rank as an int64 array [n_keyframes, levels, 2] = (index, float32 score bits), in
+    keyframe order."""
+    table = new_keyframe_table(n_keyframes, levels)
+    for kf in keyframe_share(n_keyframes, rank, world):
+        res = process_keyframe(kf)
+        if len(res) != levels:
+            raise ValueError("process_keyframe must return one (index, score) per level")
+        for lvl, (idx, score) in enumerate(res):
+            store_keyframe_result(table, kf, lvl, idx, score)
+    return gather_keyframe_table(table, world, dist, device, group)
+
+
+def unpack_keyframe_results(table):
+    """[n_keyframes, levels, 2] -> list over keyframes of [(index, float32 score)] per level."""
+    return [[(int(i), np.array([b], np.uint32).view(np.float32)[0]) for i, b in kf] for kf in table]

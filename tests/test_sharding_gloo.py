@@ -109,3 +109,73 @@ def test_sharded_argmax_over_gloo(world, case, tmp_path):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {rank} failed:\\n{out}"
         assert f"rank {rank} ok" in out
+
+
+def test_keyframe_share_is_a_partition():
+    for n in (0, 1, 7, 100):
+        for world in (1, 2, 3, 8):
+            shares = [sharding.keyframe_share(n, r, world) for r in range(world)]
+            assert sorted(k for s in shares for k in s) == list(range(n))
+            assert max(map(len, shares)) - min(map(len, shares)) <= 1
+    assert sharding.keyframe_share(100, 3, 8)[:3] == [3, 11, 19]   # BASELINE.json configs[4]: 100 keyframes over 8 ranks
+    with pytest.raises(ValueError):
+        sharding.keyframe_share(10, 2, 2)
+
+
+KEYFRAME_WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, os.environ["NMI_ROOT"])
+    from oracle import binding as oc
+    from orbslam2_nmi_amd import sharding, synthetic as sy
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_kf, levels = 7, 3
+    calls = []
+    def process_keyframe(kf):   # the per-keyframe coarse-to-fine loop (Tracking.cc:2088-2130) with the CPU oracle as the scorer
+        calls.append(kf)
+        B = sy.scene(64, 48, 300 + kf)
+        F = sy.camera_frame(B, 400 + kf)
+        out = []
+        for lvl in range(levels):
+            rs = sy.render_stack(B, (2, 2, 1), shift_px=max(1, 4 >> lvl))
+            ws = sy.warp_stack(F, (1, 1, 3), tuple(s / 2 ** lvl for s in (0.02, 0.02, 0.05)))
+            _, idx, best = oc.search_grid(rs, ws, render_bottom_up=False)
+            out.append((idx, best))
+        return out
+    table = sharding.run_keyframes(n_kf, levels, rank, world, process_keyframe, dist)
+    assert calls == sharding.keyframe_share(n_kf, rank, world), (rank, calls)          # only this rank's share was computed
+    got = sharding.unpack_keyframe_results(table)
+    calls.clear()
+    expect = [process_keyframe(kf) for kf in range(n_kf)]                               # the whole sequence on one rank
+    assert got == [[(i, np.float32(s)) for i, s in kf] for kf in expect], (rank, got[:2], expect[:2])
+    dist.barrier(); dist.destroy_process_group()
+    print("rank", rank, "ok", len(got))
+""")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_keyframe_stream_orchestration_over_gloo(world, tmp_path):
+    """The multi-rank form of BASELINE.json configs[4] (bench.py --config stream|e2e with WORLD_SIZE > 1): keyframes dealt
+    round-robin, every rank runs the per-keyframe level loop on its share, results gathered in keyframe order and equal to
+    the single-rank sequence."""
+    script = tmp_path / "kf_worker.py"
+    script.write_text(KEYFRAME_WORKER)
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   NMI_ROOT=ROOT, OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out.decode())
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {rank} failed:\\n{out}"
+        assert f"rank {rank} ok" in out

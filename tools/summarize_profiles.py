@@ -32,4 +32,22 @@ if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
     json.dump({"hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected_x2": fetch, "write_bytes": write,
                "note": "L2-fabric side counters (TCC_EA0): Infinity-Cache hits are included, so this is an upper bound on HBM bytes",
                "source": os.path.basename(out)}, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+if "SQ_LDS_IDX_ACTIVE" in summary and "SQ_INSTS_LDS" in summary:
+    # LDS side of the dominant kernel (what actually bounds it).  SQ counters tick in units of 4 cycles
+    # summed over the CUs' SIMDs.  Conflict-free reference: a 64-lane ds_add_u32 is served as 2 groups of 32 lanes, one
+    # LDS-array cycle each when no two lanes of a group meet in a bank (MI355X_MICROARCH.md section LDS, ds_write_b32 row).
+    insts = summary["SQ_INSTS_LDS"]["mean"]
+    active = summary["SQ_LDS_IDX_ACTIVE"]["mean"]
+    conflict = summary["SQ_LDS_BANK_CONFLICT"]["mean"]
+    json.dump({"lds_wave_instructions_per_launch": insts, "lds_idx_active_cycles_per_launch": active,
+               "lds_bank_conflict_cycles_per_launch": conflict, "conflict_ratio": conflict / active if active else None,
+               "lds_active_cycles_per_wave_instruction": active / insts if insts else None,
+               "conflict_free_cycles_per_wave_instruction": 2.0,
+               "note": "SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT / SQ_INSTS_LDS per launch of nmi_grid_kernel (rocprofv3 --pmc, own pass); "
+                       "conflict-free rate from MI355X_MICROARCH.md section LDS (2 x 32 lanes, one LDS-array cycle per group)",
+               "source": os.path.basename(out)}, open(os.path.join(out, "pmc_lds.json"), "w"), indent=1)
+for cfg in ("c3", "c4"):
+    stats = glob.glob(os.path.join(out, "trace_" + cfg, "*", "*_kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], os.path.join(out, f"kernel_stats_{cfg}.csv"))
 print(json.dumps(summary, indent=1)[:1500])
