@@ -73,15 +73,32 @@ int ensure_order(nmi_ctx *ctx, int S, int Wn, const int **d_order)
     return NMI_OK;
 }
 
-// How many parts the split kernel should cut each candidate into for a launch of `total` candidates on `cap`
-// workgroups: the largest of 8 / 4 / 2 whose units all run at once, 0 = use the one-workgroup-per-candidate kernel.
-static int choose_split(const nmi_ctx *ctx, int64_t total, int cap)
+// How the split kernel should cut each candidate of a launch of `total` candidates on `cap` workgroups: *parts row
+// parts (8 / 4 / 2: the largest whose workgroups all run at once) and, for the smallest grids, *pix_parts pixel ranges
+// (4 / 2, only with 8 row parts).  *parts = 0: use the one-workgroup-per-candidate kernel.
+static void choose_split(const nmi_ctx *ctx, int64_t total, int cap, int *parts, int *pix_parts)
 {
-    if (ctx->hist_variant != 3 || ctx->split_mode == 0 || total <= 0) return 0;
-    if (ctx->split_mode > 0) return nmi::split_workgroups((int)total, ctx->split_mode) <= cap ? ctx->split_mode : 0;
-    for (int k = 8; k >= 2; k >>= 1)
-        if (total * k <= cap && nmi::split_workgroups((int)total, k) <= ((cap + 7) & ~7)) return k;
-    return 0;
+    *parts = 0;
+    *pix_parts = 1;
+    if (ctx->hist_variant != 3 || ctx->split_mode == 0 || total <= 0 || total > cap) return;
+    const int cap8 = (cap + 7) & ~7;
+    auto fits = [&](int k, int p) { return total * k * p <= cap && nmi::split_workgroups((int)total, k * p) <= cap8; };
+    if (ctx->split_mode > 0) {
+        if (!fits(ctx->split_mode, 1)) return;
+        *parts = ctx->split_mode;
+    } else {
+        for (int k = 8; k >= 2 && !*parts; k >>= 1)
+            if (fits(k, 1)) *parts = k;
+        if (!*parts) return;
+    }
+    if (*parts == 8 && ctx->split_pixels != 1) {
+        if (ctx->split_pixels > 1) {
+            if (fits(8, ctx->split_pixels)) *pix_parts = ctx->split_pixels;
+        } else {
+            for (int p = 4; p >= 2 && *pix_parts == 1; p >>= 1)
+                if (fits(8, p)) *pix_parts = p;
+        }
+    }
 }
 
 static int ensure_slabs(nmi_ctx *ctx, int n)
@@ -97,6 +114,20 @@ static int ensure_slabs(nmi_ctx *ctx, int n)
     NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_slabs, (size_t)cap * sizeof(nmi::SplitSlab)));
     NMI_HIP_TRY(ctx, hipMemsetAsync(ctx->d_slabs, 0, (size_t)cap * sizeof(nmi::SplitSlab), ctx->stream));  // tickets start at 0
     ctx->slab_cap = cap;
+    return NMI_OK;
+}
+
+static int ensure_blocks(nmi_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->blocks_bytes) return NMI_OK;
+    if (ctx->d_blocks) {
+        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        NMI_HIP_TRY(ctx, hipFree(ctx->d_blocks));
+        ctx->d_blocks = nullptr;
+        ctx->blocks_bytes = 0;
+    }
+    NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_blocks, bytes));
+    ctx->blocks_bytes = bytes;
     return NMI_OK;
 }
 
@@ -158,13 +189,16 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
         return NMI_OK;
     }
     const int cap = ctx->workgroups > 0 ? ctx->workgroups : ctx->compute_units;
-    const int parts = choose_split(ctx, total, cap);
+    int parts = 0, pix_parts = 1;
+    choose_split(ctx, total, cap, &parts, &pix_parts);
     int workgroups = (int)(total < cap ? total : cap);
     if (parts) {
-        const int rs = ensure_slabs(ctx, (int)total);
+        int rs = ensure_slabs(ctx, (int)total);
+        if (rs == NMI_OK && pix_parts > 1) rs = ensure_blocks(ctx, (size_t)total * nmi::split_block_bytes_per_candidate(pix_parts));
         if (rs != NMI_OK) return rs;
         a.slabs = ctx->d_slabs;
-        workgroups = nmi::split_workgroups((int)total, parts);
+        a.blocks = ctx->d_blocks;
+        workgroups = nmi::split_workgroups((int)total, parts * pix_parts);
     } else if (ctx->xcd_tiling && total <= (1ll << 24)) {  // 4 B per candidate
         const int orc = ensure_order(ctx, S_local, Wn, &a.order);
         if (orc != NMI_OK) return orc;
@@ -183,7 +217,7 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
 #endif
     if (ctx->profiling) NMI_HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     if (parts)
-        NMI_HIP_TRY(ctx, nmi::launch_split(a, parts, workgroups, p.use_bg != 0, ctx->stream));
+        NMI_HIP_TRY(ctx, nmi::launch_split(a, parts, pix_parts, workgroups, p.use_bg != 0, ctx->stream));
     else
         NMI_HIP_TRY(ctx, nmi::launch_grid(a, workgroups, p.use_bg != 0, ctx->stream));
     // accepted: commit the protocol state
@@ -411,6 +445,7 @@ int nmi_destroy(nmi_ctx *ctx)
     if (ctx->d_reduced_key) (void)hipFree(ctx->d_reduced_key);
     if (ctx->score_mailbox) (void)hipHostFree(ctx->score_mailbox);
     if (ctx->d_slabs) (void)hipFree(ctx->d_slabs);
+    if (ctx->d_blocks) (void)hipFree(ctx->d_blocks);
     if (ctx->d_keys) (void)hipFree(ctx->d_keys);
     if (ctx->d_done) (void)hipFree(ctx->d_done);
     if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
@@ -468,6 +503,10 @@ int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value)
     case NMI_OPT_SPLIT:
         if (value != -1 && value != 0 && value != 2 && value != 4 && value != 8) return NMI_ERR_INVALID_ARGUMENT;
         ctx->split_mode = (int)value;
+        return NMI_OK;
+    case NMI_OPT_SPLIT_PIXELS:
+        if (value != -1 && value != 1 && value != 2 && value != 4) return NMI_ERR_INVALID_ARGUMENT;
+        ctx->split_pixels = (int)value;
         return NMI_OK;
     case NMI_OPT_STAMPS:
         ctx->dbg_stamps = (unsigned long long *)(uintptr_t)value;

@@ -63,6 +63,9 @@ struct nmi_ctx {
     int xcd_tiling = 1;                   // NMI_OPT_XCD_TILING
     nmi::SplitSlab *d_slabs = nullptr;    // hand-off slabs of the split kernel, one per candidate
     int slab_cap = 0;
+    uint32_t *d_blocks = nullptr;         // counter blocks of the split kernel's pixel parts
+    size_t blocks_bytes = 0;
+    int split_pixels = -1;                // NMI_OPT_SPLIT_PIXELS: -1 automatic, 1 / 2 / 4
     unsigned long long *dbg_stamps = nullptr;  // NMI_OPT_STAMPS
     int split_mode = -1;                  // NMI_OPT_SPLIT: -1 automatic, 0 never, 2 / 4 / 8 parts whenever the grid fits
     uint32_t *d_zbuf = nullptr;           // depth|colour anchor buffers of the point-cloud renderer (padded, per view)

@@ -44,6 +44,7 @@ struct GridArgs {
     unsigned int seq;               // sequence number of this posting launch (its parity is posted with the winner)
     unsigned long long *score_post; // nmi_eval_pair: pinned host word that receives (score bits | seq << 32), or nullptr
     struct SplitSlab *slabs;        // split kernel: one hand-off slab per candidate (see nmi_split_kernel.hip)
+    uint32_t *blocks;               // split kernel with pixel parts: [candidate][row part][pixel part][256 / K rows][256] counters
     unsigned long long *dbg_stamps; // tools only (NMI_OPT_STAMPS): [workgroup][8] wall_clock64 stamps at phase boundaries
     uint32_t *dbg_joint, *dbg_h1, *dbg_h2;
     float *dbg_sums;
@@ -75,11 +76,15 @@ struct SplitSlab {
     float row_sums[256];        // joint-row entropy sums (d_JointEntropyShort, kernel.cu:60,90), each row by its owner
     uint32_t hist_render[256];  // render marginal = row sums of the counts, each row by its owner
     uint32_t hw_part[8][256];   // frame marginal: column sums over the rows of each part
-    uint32_t ticket;            // arrivals; the last part to arrive scores the candidate and resets it
-    uint32_t pad[63];
+    uint32_t ticket;            // arrivals of row parts; the last one to arrive scores the candidate and resets it
+    uint32_t ticket1[8];        // per row part: arrivals of its pixel parts (pix_parts > 1); the last one merges and resets it
+    uint32_t pad[55];
 };
-hipError_t launch_split(const GridArgs &a, int parts, int workgroups, bool use_bg, hipStream_t stream);
-int split_workgroups(int candidates, int parts);  // grid size that keeps the parts of a candidate on one XCD
+// pix_parts (1, 2 or 4; > 1 only with parts = 8): the pixels of the pair are additionally cut into that many ranges, one
+// workgroup per (row part, pixel range); the workgroups of a row part merge their counters through `blocks`.
+hipError_t launch_split(const GridArgs &a, int parts, int pix_parts, int workgroups, bool use_bg, hipStream_t stream);
+int split_workgroups(int candidates, int parts_times_pix_parts);  // grid size that keeps a candidate's workgroups on one XCD
+inline size_t split_block_bytes_per_candidate(int pix_parts) { return (size_t)pix_parts * 256 * 256 * sizeof(uint32_t); }
 int grid_kernel_lds_bytes();
 size_t grid_kernel_scratch_bytes(int workgroups);
 hipError_t launch_warp(const uint8_t *frame, const float *coeffs /*[Wn][9] inverse maps*/, uint8_t *out, int width,

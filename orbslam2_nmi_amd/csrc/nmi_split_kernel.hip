@@ -18,6 +18,13 @@
 // part that arrives last; it reads the slab with sc1 loads, sums the K column partials (integers: order-free), runs the
 // three 256-element trees of AddVectorPairwiseKernel (NMI.cu:290-339) in the reference's order and forms the score.
 // Results are bit-identical to nmi_grid_kernel's (tests/test_gpu_parity.py runs every grid test through both).
+// Pixel parts (P = 2 or 4, with K = 8, for the smallest grids: one pair = 32 workgroups).  A part's time is its instruction
+// stream over ALL pixels (an LDS atomic issues at one per ~6 cycles per CU however few lanes take part; 4800 of them
+// per 640x480 pair = 12 us), so for 1..16 candidates the pixels are cut as well: workgroup (row part j, pixel range q)
+// counts range q's pixels into rows j.  The P workgroups of a row part then merge: each stores its 32 KiB block of
+// counters to global memory (sc1), draws a ticket, and the one that arrives last adds the other P - 1 blocks to its
+// own and carries on as the row part's owner (decode, slab, second ticket) -- whole rows again, so everything
+// downstream is unchanged and results stay bit-identical.
 // Hand-off form: MI355X_MICROARCH.md "inter-workgroup visibility", table row 1 (sc1 stores -> every wave s_waitcnt
 // vmcnt(0) -> workgroup barrier -> one agent-scope atomic add; the adder that came last loads after its add returned,
 // the other waves after a barrier).  One workgroup per CU (LDS padded) as that row requires.
@@ -157,13 +164,18 @@ __device__ __forceinline__ void add_chunk_careful(uint32_t *joint, const uint4 &
 // only the pixels whose render intensity belongs to this part's rows.
 template <int K, bool FAST>
 __device__ __forceinline__ void histogram_split(uint32_t *joint, const GridArgs &a, const uint8_t *__restrict__ render,
-                                                const uint8_t *__restrict__ warped, int tid, int part, bool use_bg)
+                                                const uint8_t *__restrict__ warped, int tid, int part, bool use_bg, int pix_part,
+                                                int pix_parts)
 {
     constexpr int NT = kBlock;
     constexpr uint32_t kRows = kBins / K;
     if (a.vec_ok) {
-        const int nchunks = a.npix >> 4;
-        const int last = nchunks - 1;
+        const int all_chunks = a.npix >> 4;
+        const int last = all_chunks - 1;
+        // this workgroup's pixel range, in 16-pixel chunks: [first, nchunks)
+        const int per_part = (all_chunks + pix_parts - 1) / pix_parts;
+        const int first = min(pix_part * per_part, all_chunks);
+        const int nchunks = min(first + per_part, all_chunks);
         auto ldw = [&](int c) { return *reinterpret_cast<const uint4 *>(warped + ((uint32_t)min(c, last) << 4)); };
         // NMI.cu:82: row y of the frame meets row H-1-y of a bottom-up render (see histogram_phase in nmi_kernels.hip)
         auto ldr = [&](int c) {
@@ -179,9 +191,9 @@ __device__ __forceinline__ void histogram_split(uint32_t *joint, const GridArgs 
             // dword in both images for the whole wavefront) sends the wavefront to the careful loop for the rest of the
             // candidate.
             const uint32_t xorpat = (uint32_t)part * kRows * 0x01010101u;
-            const int iters = (nchunks + 2 * NT - 1) / (2 * NT);  // workgroup-uniform
+            const int iters = (nchunks - first + 2 * NT - 1) / (2 * NT);  // workgroup-uniform
             int resume = -1;
-            int ch = tid;
+            int ch = first + tid;
             uint4 wa0 = ldw(ch), ra0 = ldr(ch), wa1 = ldw(ch + NT), ra1 = ldr(ch + NT), wb0, rb0, wb1, rb1;
             const bool fold = !(a.phase_mask & 4);
 #define NMI_SPLIT_STEP(RC, WC, OFF)                                          \
@@ -218,9 +230,9 @@ __device__ __forceinline__ void histogram_split(uint32_t *joint, const GridArgs 
             }
         } else {
             // BG off and / or reduced bins: per-pixel form on 16-byte loads, one chunk of prefetch
-            uint4 wc = ldw(tid), rc = ldr(tid);
+            uint4 wc = ldw(first + tid), rc = ldr(first + tid);
 #pragma unroll 1
-            for (int c = tid; c < nchunks; c += NT) {
+            for (int c = first + tid; c < nchunks; c += NT) {
                 const uint4 wn = ldw(c + NT), rn = ldr(c + NT);
                 const uint32_t r[4] = {rc.x, rc.y, rc.z, rc.w}, w[4] = {wc.x, wc.y, wc.z, wc.w};
 #pragma unroll
@@ -234,7 +246,9 @@ __device__ __forceinline__ void histogram_split(uint32_t *joint, const GridArgs 
         }
     } else {
         // Any width / alignment: byte loads, position arithmetic as written in NMI.cu:79-83.
-        for (int pos = tid; pos < a.npix; pos += NT) {
+        const int per_part = (a.npix + pix_parts - 1) / pix_parts;
+        const int pos0 = min(pix_part * per_part, a.npix), pos1 = min(pos0 + per_part, a.npix);
+        for (int pos = pos0 + tid; pos < pos1; pos += NT) {
             const int y = pos / a.width;
             const int x = pos - y * a.width;
             const int ry = a.flip ? (a.height - 1 - y) : y;
@@ -362,7 +376,48 @@ __device__ __forceinline__ void final_split(const SplitLds<K> &lds, const GridAr
 // Unit u of a launch = (candidate, part).  Candidates are taken in groups of 8, one per XCD (workgroups are dealt to the
 // XCDs round-robin: blocks b and b + 8 share one), and the K parts of a candidate are the blocks b, b + 8, ... of that
 // XCD, so they read the pair from one L2.  Placement is a speed matter only.
-template <int K, bool FAST>
+// Merge of the pixel parts of one row part (P > 1).  Every workgroup stores its block of counters (sc1, 8 bytes per
+// store), all waves wait for their stores, one lane draws the row part's ticket.  Returns true in the workgroup that
+// arrived last, with the other P - 1 blocks added into its LDS counters; false elsewhere (counters cleared).
+template <int K, int P>
+__device__ __forceinline__ bool merge_pixel_parts(SplitLds<K> &lds, const GridArgs &a, SplitSlab *slab, int cand, int part, int pix_part, int tid)
+{
+    constexpr int kRows = kBins / K;
+    constexpr int kPairs = kRows * kBins / 2;  // 8-byte units per block
+    unsigned long long *const mine = reinterpret_cast<unsigned long long *>(a.blocks) + ((size_t)(cand * K + part) * P + pix_part) * kPairs;
+    unsigned long long *const j2 = reinterpret_cast<unsigned long long *>(lds.joint);
+    for (int i = tid; i < kPairs; i += kBlock) __hip_atomic_store(&mine[i], j2[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int arrived = __hip_atomic_fetch_add(&slab->ticket1[part], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = arrived == (unsigned int)(P - 1);
+        if (last) __hip_atomic_store(&slab->ticket1[part], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lds.is_last = last ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool last = lds.is_last != 0;
+    if (last) {
+        const unsigned long long *const base = reinterpret_cast<const unsigned long long *>(a.blocks) + (size_t)(cand * K + part) * P * kPairs;
+        for (int i = tid; i < kPairs; i += kBlock) {
+            unsigned long long acc = j2[i];
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                if (q == pix_part) continue;
+                const unsigned long long v = __hip_atomic_load(&base[(size_t)q * kPairs + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // two 32-bit counters per unit: add without a carry between them
+                acc = (((acc & 0xFFFFFFFFull) + (v & 0xFFFFFFFFull)) & 0xFFFFFFFFull) | (((acc >> 32) + (v >> 32)) << 32);
+            }
+            j2[i] = acc;
+        }
+    } else {
+        for (int i = tid; i < kPairs; i += kBlock) j2[i] = 0ull;
+    }
+    __syncthreads();  // the merged counters are complete before decode; is_last is free for the second ticket
+    return last;
+}
+
+template <int K, int P, bool FAST>
 __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_split_kernel(GridArgs a, int use_bg)
 {
     __shared__ SplitLds<K> lds;
@@ -387,11 +442,11 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_split_kernel(GridArgs a
     __syncthreads();
 
     const int total = a.S_local * a.Wn;
-    const int units = ((total + 7) >> 3) * 8 * K;
+    const int units = ((total + 7) >> 3) * 8 * K * P;
     unsigned long long prev_key = 0;
     for (int u = blockIdx.x; u < units; u += gridDim.x) {
         const int x = u & 7, t = u >> 3;
-        const int part = t % K, p = (t / K) * 8 + x;
+        const int sub = t % (K * P), part = sub % K, pix_part = sub / K, p = (t / (K * P)) * 8 + x;
         if (p >= total) continue;  // workgroup-uniform
         const int w = p / a.S_local, s = p - w * a.S_local;
         SplitSlab *slab = a.slabs + p;
@@ -399,9 +454,10 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_split_kernel(GridArgs a
         stamp(1);
         if (a.phase_mask & 1)
             histogram_split<K, FAST>(lds.joint, a, a.render_stack + (size_t)s * a.npix, a.warp_stack + (size_t)w * a.npix, tid, part,
-                                     use_bg != 0);
+                                     use_bg != 0, pix_part, P);
         __syncthreads();
         stamp(2);
+        if (P > 1 && !merge_pixel_parts<K, P>(lds, a, slab, p, part, pix_part, tid)) continue;  // workgroup-uniform
         decode_split<K>(lds, a, slab, part, wave, lane);
         __syncthreads();
         stamp(3);
@@ -436,28 +492,36 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_split_kernel(GridArgs a
     if (a.dbg_stamps && tid == 0) a.dbg_stamps[blockIdx.x * 8 + 7] = (unsigned long long)(clock64() - clk0);
 }
 
-int split_workgroups(int candidates, int parts) { return ((candidates + 7) / 8) * 8 * parts; }
+int split_workgroups(int candidates, int parts_times_pix_parts) { return ((candidates + 7) / 8) * 8 * parts_times_pix_parts; }
 
-template <int K>
+template <int K, int P>
 static void launch_split_k(const GridArgs &a, dim3 grid, dim3 block, bool use_bg, hipStream_t stream)
 {
     const bool fast = use_bg && a.shift == 0;
     if (fast)
-        hipLaunchKernelGGL((nmi_split_kernel<K, true>), grid, block, 0, stream, a, 1);
+        hipLaunchKernelGGL((nmi_split_kernel<K, P, true>), grid, block, 0, stream, a, 1);
     else
-        hipLaunchKernelGGL((nmi_split_kernel<K, false>), grid, block, 0, stream, a, use_bg ? 1 : 0);
+        hipLaunchKernelGGL((nmi_split_kernel<K, P, false>), grid, block, 0, stream, a, use_bg ? 1 : 0);
 }
 
-hipError_t launch_split(const GridArgs &a, int parts, int workgroups, bool use_bg, hipStream_t stream)
+hipError_t launch_split(const GridArgs &a, int parts, int pix_parts, int workgroups, bool use_bg, hipStream_t stream)
 {
     if (!a.slabs || workgroups <= 0 || (workgroups & 7)) return hipErrorInvalidValue;
+    if (pix_parts > 1 && (parts != 8 || !a.blocks)) return hipErrorInvalidValue;
     dim3 grid(workgroups), block(kBlock);
-    switch (parts) {
-    case 2: launch_split_k<2>(a, grid, block, use_bg, stream); break;
-    case 4: launch_split_k<4>(a, grid, block, use_bg, stream); break;
-    case 8: launch_split_k<8>(a, grid, block, use_bg, stream); break;
-    default: return hipErrorInvalidValue;
-    }
+    if (pix_parts == 4)
+        launch_split_k<8, 4>(a, grid, block, use_bg, stream);
+    else if (pix_parts == 2)
+        launch_split_k<8, 2>(a, grid, block, use_bg, stream);
+    else if (pix_parts != 1)
+        return hipErrorInvalidValue;
+    else
+        switch (parts) {
+        case 2: launch_split_k<2, 1>(a, grid, block, use_bg, stream); break;
+        case 4: launch_split_k<4, 1>(a, grid, block, use_bg, stream); break;
+        case 8: launch_split_k<8, 1>(a, grid, block, use_bg, stream); break;
+        default: return hipErrorInvalidValue;
+        }
     return hipGetLastError();
 }
 

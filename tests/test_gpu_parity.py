@@ -35,12 +35,21 @@ def dev(a):
 # Kernel selection for small grids (NMI_OPT_SPLIT): -1 automatic (K = 8 / 4 / 2 workgroups per candidate when the grid
 # leaves compute units idle), 0 the one-workgroup-per-candidate kernel only, 8 / 4 / 2 forced.  Tests that take this
 # fixture run once per mode; results must be identical bit for bit.
-@pytest.fixture(params=[-1, 0, 8, 4, 2], ids=lambda m: {-1: "auto", 0: "nosplit"}.get(m, f"split{m}"))
+# A tuple (8, P) additionally forces P pixel ranges per row part (NMI_OPT_SPLIT_PIXELS); plain 8 / 4 / 2 run without them.
+@pytest.fixture(params=[-1, 0, (8, 4), (8, 2), 8, 4, 2],
+                ids=lambda m: {-1: "auto", 0: "nosplit"}.get(m, f"split{m[0]}x{m[1]}" if isinstance(m, tuple) else f"split{m}"))
 def split_mode(request, nmi):
     from orbslam2_nmi_amd import capi
-    capi.NmiContext.default_options = {capi.NmiContext.OPT_SPLIT: request.param}
-    yield request.param
-    capi.NmiContext.default_options = {}
+    m = request.param
+    C = capi.NmiContext
+    if isinstance(m, tuple):
+        C.default_options = {C.OPT_SPLIT: m[0], C.OPT_SPLIT_PIXELS: m[1]}
+    elif m == -1:
+        C.default_options = {C.OPT_SPLIT: -1}
+    else:
+        C.default_options = {C.OPT_SPLIT: m, C.OPT_SPLIT_PIXELS: 1}
+    yield m
+    C.default_options = {}
 
 
 @pytest.fixture(params=[-1, 0], ids=["auto", "nosplit"])

@@ -23,6 +23,8 @@ for S, Wn in grids:
         with nmi.NmiContext(w, h) as ctx:
             ctx.set_stream(stream.cuda_stream)
             ctx.set_option(ctx.OPT_SPLIT, mode)
+            if mode > 0:
+                ctx.set_option(ctx.OPT_SPLIT_PIXELS, 1)
             for _ in range(20):
                 got = ctx.search_grid(r, v)
             ref = ref or got

@@ -13,14 +13,16 @@ S = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 Wn = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 MASK = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+P = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 w, h = 640, 480
 wl = sy.workload(w, h, 27, 27, seed=1234)
 rs, ws = torch.from_numpy(wl["render_stack"]).cuda()[:S].contiguous(), torch.from_numpy(wl["warp_stack"]).cuda()[:Wn].contiguous()
 names = ["start", "zeroed", "hist", "decode", "ticket", "final", "end"]
 with nmi.NmiContext(w, h) as ctx:
     ctx.set_option(ctx.OPT_SPLIT, K)
+    ctx.set_option(ctx.OPT_SPLIT_PIXELS, P)
     ctx.set_option(ctx.OPT_PHASE_MASK, MASK)
-    n_wg = ((S * Wn + 7) // 8) * 8 * K
+    n_wg = ((S * Wn + 7) // 8) * 8 * K * P
     st = torch.zeros((n_wg, 8), dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
     for rep in range(5):
