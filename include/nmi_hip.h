@@ -294,9 +294,10 @@ int nmi_last_kernel_ms(nmi_ctx *ctx, float *h_ms);
                                   (lowest latency, occupies the calling core for the search), 1 yields the core between
                                   polls (sched_yield; for hosts whose other threads need the core, e.g. ORB-SLAM2's
                                   LocalMapping / LoopClosing).  NMI_OPT_RESULT_PATH 0 sleeps in hipStreamSynchronize instead. */
-#define NMI_OPT_SPLIT_PIXELS 10 /* with 8 row parts, additionally cut the pixels of each pair into 2 or 4 ranges (one workgroup per
-                                  row part and range, merged per row part: nmi_eval_pair = 32 workgroups).  -1 (default): 4 / 2
-                                  when candidates * 8 * ranges <= compute units; 1: never; 2 / 4: that many when it fits. */
+#define NMI_OPT_SPLIT_PIXELS 10 /* with 8 row parts, additionally cut the pixels of each pair into 2, 4 or 8 ranges (one workgroup
+                                  per row part and range, merged per row part: nmi_eval_pair = 64 workgroups).  -1 (default):
+                                  the largest of 8 / 4 / 2 with candidates * 8 * ranges <= compute units; 1: never; 2 / 4 / 8:
+                                  that many when it fits. */
 #define NMI_OPT_STAMPS 9       /* profiling tools only: value = device pointer to uint64 [workgroups][8]; workgroups of the
                                   split kernel store wall-clock stamps (100 MHz) at their phase boundaries there; 0 = off */
 int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value);

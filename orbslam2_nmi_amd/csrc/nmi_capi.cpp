@@ -95,10 +95,25 @@ static void choose_split(const nmi_ctx *ctx, int64_t total, int cap, int *parts,
         if (ctx->split_pixels > 1) {
             if (fits(8, ctx->split_pixels)) *pix_parts = ctx->split_pixels;
         } else {
-            for (int p = 4; p >= 2 && *pix_parts == 1; p >>= 1)
+            for (int p = 8; p >= 2 && *pix_parts == 1; p >>= 1)
                 if (fits(8, p)) *pix_parts = p;
         }
     }
+}
+
+// Epoch of the next split launch.  Slab granules carry all 32 bits, block granules the low 16: neither may be 0 (the
+// cleared state), and whenever the low 16 bits wrap the blocks are cleared so that no granule older than 65535 launches
+// can show the current tag (the slabs likewise when all 32 bits wrap).
+static int next_split_epoch(nmi_ctx *ctx, uint32_t *epoch)
+{
+    uint32_t e = ctx->split_epoch + 1;
+    if ((e & 0xFFFFu) == 0) {
+        if (ctx->d_blocks) NMI_HIP_TRY(ctx, hipMemsetAsync(ctx->d_blocks, 0, ctx->blocks_bytes, ctx->stream));
+        if (e == 0 && ctx->d_slabs) NMI_HIP_TRY(ctx, hipMemsetAsync(ctx->d_slabs, 0, (size_t)ctx->slab_cap * sizeof(nmi::SplitSlab), ctx->stream));
+        ++e;
+    }
+    ctx->split_epoch = *epoch = e;
+    return NMI_OK;
 }
 
 static int ensure_slabs(nmi_ctx *ctx, int n)
@@ -112,7 +127,7 @@ static int ensure_slabs(nmi_ctx *ctx, int n)
     }
     const int cap = n > 128 ? n : 128;
     NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_slabs, (size_t)cap * sizeof(nmi::SplitSlab)));
-    NMI_HIP_TRY(ctx, hipMemsetAsync(ctx->d_slabs, 0, (size_t)cap * sizeof(nmi::SplitSlab), ctx->stream));  // tickets start at 0
+    NMI_HIP_TRY(ctx, hipMemsetAsync(ctx->d_slabs, 0, (size_t)cap * sizeof(nmi::SplitSlab), ctx->stream));  // epoch 0 = never written
     ctx->slab_cap = cap;
     return NMI_OK;
 }
@@ -127,6 +142,7 @@ static int ensure_blocks(nmi_ctx *ctx, size_t bytes)
         ctx->blocks_bytes = 0;
     }
     NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_blocks, bytes));
+    NMI_HIP_TRY(ctx, hipMemsetAsync(ctx->d_blocks, 0, bytes, ctx->stream));  // tag 0 = never written
     ctx->blocks_bytes = bytes;
     return NMI_OK;
 }
@@ -190,14 +206,20 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     }
     const int cap = ctx->workgroups > 0 ? ctx->workgroups : ctx->compute_units;
     int parts = 0, pix_parts = 1;
-    choose_split(ctx, total, cap, &parts, &pix_parts);
+    // the split kernel's consumers wait for their producers inside the launch: all its workgroups must be able to run at
+    // once, i.e. no more of them than compute units (each takes a whole CU)
+    choose_split(ctx, total, cap < ctx->compute_units ? cap : ctx->compute_units, &parts, &pix_parts);
+    if (pix_parts > 1 && ctx->npix >= (1 << 24)) pix_parts = 1;  // block granules hold 24-bit counts
     int workgroups = (int)(total < cap ? total : cap);
     if (parts) {
         int rs = ensure_slabs(ctx, (int)total);
         if (rs == NMI_OK && pix_parts > 1) rs = ensure_blocks(ctx, (size_t)total * nmi::split_block_bytes_per_candidate(pix_parts));
         if (rs != NMI_OK) return rs;
+        if (rs == NMI_OK) rs = next_split_epoch(ctx, &a.epoch);
+        if (rs != NMI_OK) return rs;
         a.slabs = ctx->d_slabs;
         a.blocks = ctx->d_blocks;
+        a.split_error = ctx->d_split_error;
         workgroups = nmi::split_workgroups((int)total, parts * pix_parts);
     } else if (ctx->xcd_tiling && total <= (1ll << 24)) {  // 4 B per candidate
         const int orc = ensure_order(ctx, S_local, Wn, &a.order);
@@ -232,6 +254,19 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
         ctx->have_timing = true;
     }
     return NMI_OK;
+}
+
+// A hand-off of the split kernel timed out (its workgroups could not all run at once -- e.g. the device exposes fewer
+// compute units to this process than it reports): wait for the launch to drain, switch the split forms off for this
+// context and tell the caller to redo the call, which then goes through nmi_grid_kernel.
+bool split_timed_out(nmi_ctx *ctx)
+{
+    if (!ctx->last_parts || !__atomic_load_n(ctx->h_split_error, __ATOMIC_ACQUIRE)) return false;
+    (void)hipStreamSynchronize(ctx->stream);
+    *ctx->h_split_error = 0;
+    ctx->split_mode = 0;
+    ctx->detail = "split kernel hand-off timed out; split forms disabled for this context";
+    return true;
 }
 
 // Polls a pinned host word until (word & mask) == want; *out receives the word.  NMI_OPT_WAIT_MODE 0 spins (lowest
@@ -426,6 +461,11 @@ int nmi_create(const nmi_params *params, nmi_ctx **out_ctx)
         hipSuccess)
         return fail(e, "hipHostMalloc(score mailbox)");
     memset(ctx->score_mailbox, 0, 2 * sizeof(unsigned long long));
+    if ((e = hipHostMalloc((void **)&ctx->h_split_error, 64, hipHostMallocCoherent | hipHostMallocMapped)) != hipSuccess)
+        return fail(e, "hipHostMalloc(split error)");
+    *ctx->h_split_error = 0;
+    if ((e = hipHostGetDevicePointer((void **)&ctx->d_split_error, ctx->h_split_error, 0)) != hipSuccess)
+        return fail(e, "hipHostGetDevicePointer(split error)");
     if ((e = hipHostMalloc((void **)&ctx->h_key, sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
         return fail(e, "hipHostMalloc(key)");
     if ((e = hipEventCreate(&ctx->ev_start)) != hipSuccess) return fail(e, "hipEventCreate");
@@ -446,6 +486,7 @@ int nmi_destroy(nmi_ctx *ctx)
     if (ctx->score_mailbox) (void)hipHostFree(ctx->score_mailbox);
     if (ctx->d_slabs) (void)hipFree(ctx->d_slabs);
     if (ctx->d_blocks) (void)hipFree(ctx->d_blocks);
+    if (ctx->h_split_error) (void)hipHostFree(ctx->h_split_error);
     if (ctx->d_keys) (void)hipFree(ctx->d_keys);
     if (ctx->d_done) (void)hipFree(ctx->d_done);
     if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
@@ -505,7 +546,7 @@ int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value)
         ctx->split_mode = (int)value;
         return NMI_OK;
     case NMI_OPT_SPLIT_PIXELS:
-        if (value != -1 && value != 1 && value != 2 && value != 4) return NMI_ERR_INVALID_ARGUMENT;
+        if (value != -1 && value != 1 && value != 2 && value != 4 && value != 8) return NMI_ERR_INVALID_ARGUMENT;
         ctx->split_pixels = (int)value;
         return NMI_OK;
     case NMI_OPT_STAMPS:
@@ -620,6 +661,9 @@ int nmi_search_grid_block(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S_l
         unsigned long long k = 0;
         rc = fetch_key(ctx, &k);
         if (rc != NMI_OK) return rc;
+        if (split_timed_out(ctx))
+            return nmi_search_grid_block(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn_local, w_offset, Wn_total,
+                                         d_ratings, d_key, h_key);
         *h_key = k;
         // The winner is posted by the last workgroup before the kernel has retired: a caller that asked for the rating
         // table may read it right after this call, from any stream, so the table must be complete (and written back).
@@ -652,6 +696,8 @@ int nmi_eval_pair_debug(nmi_ctx *ctx, const uint8_t *render, const uint8_t *warp
         // (score bits | call number << 32) into pinned host memory and the call polls that word (~10 us less per call).
         unsigned long long word = 0;
         rc = wait_word(ctx, ctx->score_mailbox, 0xFFFFFFFF00000000ull, (unsigned long long)ctx->pair_seq << 32, &word);
+        if (rc == NMI_OK && split_timed_out(ctx))
+            return nmi_eval_pair_debug(ctx, render, warped, h_score, d_joint, d_hist_render, d_hist_warped, d_sums);
         if (rc == NMI_OK) {
             const uint32_t bits = (uint32_t)word;
             memcpy(h_score, &bits, sizeof bits);
@@ -662,6 +708,7 @@ int nmi_eval_pair_debug(nmi_ctx *ctx, const uint8_t *render, const uint8_t *warp
     }
     NMI_HIP_TRY(ctx, hipMemcpyAsync(h_score, ctx->d_pair_rating, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (split_timed_out(ctx)) return nmi_eval_pair_debug(ctx, render, warped, h_score, d_joint, d_hist_render, d_hist_warped, d_sums);
     return NMI_OK;
 }
 

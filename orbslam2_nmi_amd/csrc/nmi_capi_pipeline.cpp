@@ -424,6 +424,7 @@ int nmi_stream_wait(nmi_stream *st, int64_t ticket, int64_t *h_best_index, float
     DeviceGuard guard(ctx->device);
     NMI_HIP_TRY(ctx, hipEventSynchronize(s.done));
     s.waited = true;
+    if (split_timed_out(ctx)) return NMI_ERR_NOT_READY;  // resubmit: the split forms are off from here on
     return nmi_key_unpack(*s.h_key, h_best_index, h_best_score);
 }
 

@@ -113,6 +113,8 @@ int nmi_search_grid_block_rccl(nmi_ctx *ctx, const uint8_t *render_stack, int32_
     if (r != 0) return rccl_fail(ctx, r, "ncclAllReduce");
     NMI_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_key, ctx->d_reduced_key, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // (a redo on this rank alone would issue a second collective; report it instead -- the split forms are now off)
+    if (split_timed_out(ctx)) return NMI_ERR_NOT_READY;
     return nmi_key_unpack(*ctx->h_key, h_best_index, h_best_score);
 }
 

@@ -63,7 +63,9 @@ struct nmi_ctx {
     int xcd_tiling = 1;                   // NMI_OPT_XCD_TILING
     nmi::SplitSlab *d_slabs = nullptr;    // hand-off slabs of the split kernel, one per candidate
     int slab_cap = 0;
-    uint32_t *d_blocks = nullptr;         // counter blocks of the split kernel's pixel parts
+    unsigned long long *d_blocks = nullptr;  // counter blocks (granules) of the split kernel's pixel parts
+    uint32_t split_epoch = 0;             // tag of the latest split launch
+    uint32_t *h_split_error = nullptr, *d_split_error = nullptr;  // pinned: raised by the kernel when a hand-off timed out
     size_t blocks_bytes = 0;
     int split_pixels = -1;                // NMI_OPT_SPLIT_PIXELS: -1 automatic, 1 / 2 / 4
     unsigned long long *dbg_stamps = nullptr;  // NMI_OPT_STAMPS
@@ -117,6 +119,7 @@ int wait_word(nmi_ctx *ctx, const volatile unsigned long long *word, unsigned lo
               unsigned long long *out);
 int stage_floats(nmi_ctx *ctx, StagingRing &ring, const float *h_src, size_t n, float **d_out);
 int fetch_key(nmi_ctx *ctx, unsigned long long *key);
+bool split_timed_out(nmi_ctx *ctx);
 int check_grid_args(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_offset, int S_total, const uint8_t *warp_stack,
                     int Wn);
 

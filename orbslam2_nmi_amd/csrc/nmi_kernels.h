@@ -44,7 +44,9 @@ struct GridArgs {
     unsigned int seq;               // sequence number of this posting launch (its parity is posted with the winner)
     unsigned long long *score_post; // nmi_eval_pair: pinned host word that receives (score bits | seq << 32), or nullptr
     struct SplitSlab *slabs;        // split kernel: one hand-off slab per candidate (see nmi_split_kernel.hip)
-    uint32_t *blocks;               // split kernel with pixel parts: [candidate][row part][pixel part][256 / K rows][256] counters
+    unsigned long long *blocks;     // split kernel with pixel parts: [candidate][row part][pixel part] blocks of 24+24+16-bit granules
+    uint32_t epoch;                 // split kernel: this launch's tag (never 0; its low 16 bits never 0)
+    uint32_t *split_error;          // pinned host word, set to 1 if a hand-off of the split kernel timed out
     unsigned long long *dbg_stamps; // tools only (NMI_OPT_STAMPS): [workgroup][8] wall_clock64 stamps at phase boundaries
     uint32_t *dbg_joint, *dbg_h1, *dbg_h2;
     float *dbg_sums;
@@ -72,19 +74,18 @@ bool ablation_variants_built();  // HIST variants 0 / 2 / 4 compiled in (-DNMI_B
 
 // Split form for grids with fewer candidates than compute units (nmi_split_kernel.hip): K workgroups per candidate, each
 // owning 256 / K complete rows (render intensities) of the joint histogram as 32-bit LDS counters.  parts = 2, 4 or 8.
+// Everything that crosses workgroups travels as 8-byte {payload, epoch} granules, each written by ONE sc1 store, so a
+// reader that finds the launch's epoch in a granule has the payload too (no flag, no release / acquire pair).
 struct SplitSlab {
-    float row_sums[256];        // joint-row entropy sums (d_JointEntropyShort, kernel.cu:60,90), each row by its owner
-    uint32_t hist_render[256];  // render marginal = row sums of the counts, each row by its owner
-    uint32_t hw_part[8][256];   // frame marginal: column sums over the rows of each part
-    uint32_t ticket;            // arrivals of row parts; the last one to arrive scores the candidate and resets it
-    uint32_t ticket1[8];        // per row part: arrivals of its pixel parts (pix_parts > 1); the last one merges and resets it
-    uint32_t pad[55];
+    unsigned long long row_sums[256];     // {float bits of the joint-row entropy sum (d_JointEntropyShort, kernel.cu:60,90), epoch}
+    unsigned long long hist_render[256];  // {render marginal count = row sum of the counts, epoch}, each row by its owner
+    unsigned long long hw_part[8][256];   // {frame marginal: column sum over the rows of one part, epoch}
 };
-// pix_parts (1, 2 or 4; > 1 only with parts = 8): the pixels of the pair are additionally cut into that many ranges, one
+// pix_parts (1, 2, 4 or 8; > 1 only with parts = 8): the pixels of the pair are additionally cut into that many ranges, one
 // workgroup per (row part, pixel range); the workgroups of a row part merge their counters through `blocks`.
 hipError_t launch_split(const GridArgs &a, int parts, int pix_parts, int workgroups, bool use_bg, hipStream_t stream);
 int split_workgroups(int candidates, int parts_times_pix_parts);  // grid size that keeps a candidate's workgroups on one XCD
-inline size_t split_block_bytes_per_candidate(int pix_parts) { return (size_t)pix_parts * 256 * 256 * sizeof(uint32_t); }
+inline size_t split_block_bytes_per_candidate(int pix_parts) { return (size_t)pix_parts * 256 * 128 * sizeof(unsigned long long); }
 int grid_kernel_lds_bytes();
 size_t grid_kernel_scratch_bytes(int workgroups);
 hipError_t launch_warp(const uint8_t *frame, const float *coeffs /*[Wn][9] inverse maps*/, uint8_t *out, int width,

@@ -14,20 +14,26 @@
 //   * the row trees of AddvectorParwiseMidKernel (NMI.cu:270-287) run per row exactly as in nmi_grid_kernel, so the
 //     256 row sums and the render marginal are final when a part stores them.
 // What crosses workgroups is small: 256/K row sums + 256/K render-marginal counts + 256 partial column sums per part
-// (2.3 KB at K = 8), written to a per-candidate slab with sc1 (L2-bypassing) stores.  A device-scope ticket tells the
-// part that arrives last; it reads the slab with sc1 loads, sums the K column partials (integers: order-free), runs the
-// three 256-element trees of AddVectorPairwiseKernel (NMI.cu:290-339) in the reference's order and forms the score.
-// Results are bit-identical to nmi_grid_kernel's (tests/test_gpu_parity.py runs every grid test through both).
+// (2.3 KB of payload at K = 8), written to a per-candidate slab.  Part 0 of a candidate is its scorer: it collects the
+// slab, sums the K column partials (integers: order-free), runs the three 256-element trees of AddVectorPairwiseKernel
+// (NMI.cu:290-339) in the reference's order and forms the score.  Results are bit-identical to nmi_grid_kernel's
+// (tests/test_gpu_parity.py runs every grid test through both).
+//
 // Pixel parts (P = 2 or 4, with K = 8, for the smallest grids: one pair = 32 workgroups).  A part's time is its instruction
 // stream over ALL pixels (an LDS atomic issues at one per ~6 cycles per CU however few lanes take part; 4800 of them
 // per 640x480 pair = 12 us), so for 1..16 candidates the pixels are cut as well: workgroup (row part j, pixel range q)
-// counts range q's pixels into rows j.  The P workgroups of a row part then merge: each stores its 32 KiB block of
-// counters to global memory (sc1), draws a ticket, and the one that arrives last adds the other P - 1 blocks to its
-// own and carries on as the row part's owner (decode, slab, second ticket) -- whole rows again, so everything
+// counts range q's pixels into rows j.  Pixel range 0 is the row part's owner: the other P - 1 workgroups send it their
+// 32 KiB block of counters, it adds them to its own and carries on (decode, slab) with whole rows again, so everything
 // downstream is unchanged and results stay bit-identical.
-// Hand-off form: MI355X_MICROARCH.md "inter-workgroup visibility", table row 1 (sc1 stores -> every wave s_waitcnt
-// vmcnt(0) -> workgroup barrier -> one agent-scope atomic add; the adder that came last loads after its add returned,
-// the other waves after a barrier).  One workgroup per CU (LDS padded) as that row requires.
+//
+// Hand-off form (both stages): data-tagged granules (MI355X_MICROARCH.md, "handoff-1to1": ~1 us per hop; "R2's granule
+// needs no ordering at all").  Every 8-byte unit carries its payload AND the launch's epoch and is written by one sc1
+// store; the consumer polls the granules it needs with sc1 loads until they show the epoch.  Nothing waits on a
+// store, no ticket is drawn: a stage costs one store -> load trip instead of store, wait, atomic, load (the ticket
+// form of this kernel's first version: 5 us for the pixel-part merge, 16 us per pair; now 2 us and 11 us).
+// The consumers spin, so every workgroup of the launch must be able to run at once: the host launches this kernel only
+// with one unit per workgroup and no more workgroups than compute units (one per CU: LDS padded), and every poll loop is
+// bounded -- on a timeout the kernel raises GridArgs::split_error and the host redoes the call with nmi_grid_kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -52,8 +58,7 @@ struct SplitLds {
     uint32_t fin_render[kBins];     // the last part's copy of the candidate's slab: render marginal,
     uint32_t fin_warped[kBins];     //   frame marginal (sum of the K column partials),
     float fin_rows[kBins];          //   joint row sums
-    uint32_t is_last;
-    uint32_t pad0[3];
+    uint32_t pad0[4];
     uint32_t pad[kUsed < kMinLdsBytes ? (kMinLdsBytes - kUsed) / 4 : 4];
 };
 
@@ -69,6 +74,21 @@ __device__ __forceinline__ uint32_t load_sc1(const uint32_t *p)
 __device__ __forceinline__ float load_sc1(const float *p)
 {
     return __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+__device__ __forceinline__ void store_granule(unsigned long long *p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dwordx2 sc1
+}
+__device__ __forceinline__ unsigned long long load_granule(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_load_dwordx2 sc1
+}
+__device__ __forceinline__ unsigned long long granule32(uint32_t payload, uint32_t epoch) { return (unsigned long long)payload | ((unsigned long long)epoch << 32); }
+constexpr int kMaxPolls = 1 << 15;  // x (load round trip + sleep) >= 30 ms: far beyond any legitimate wait, then give up
+__device__ __forceinline__ void raise_timeout(const GridArgs &a)
+{
+    if (a.split_error) __hip_atomic_store(a.split_error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // 16 pixels of one lane, hot case (BG on, 256 bins).  xorpat holds (part * kRows) in every byte: after r ^= xorpat a pixel
@@ -298,8 +318,8 @@ __device__ __forceinline__ void decode_split(SplitLds<K> &lds, const GridArgs &a
         rsum = row_sum_16(rsum);
         const float x = row_tree_16(lane_tree_16(tl, th));
         if (i == 0) {
-            store_sc1(&slab->row_sums[d1], x);
-            store_sc1(&slab->hist_render[d1], rsum);
+            store_granule(&slab->row_sums[d1], granule32(__float_as_uint(x), a.epoch));
+            store_granule(&slab->hist_render[d1], granule32(rsum, a.epoch));
         }
         if (a.dbg_joint) {
             uint32_t *out = a.dbg_joint + d1 * kBins;
@@ -321,23 +341,40 @@ __device__ __forceinline__ void decode_split(SplitLds<K> &lds, const GridArgs &a
     }
 }
 
-// The part that arrived last.  All wavefronts first fetch the candidate's slab (every load of handed-off bytes is an sc1
-// load: they were sc1 stores of other workgroups) in ONE round trip -- lane t sums the K column partials of bin t, others
-// take the render marginal and the row sums -- into LDS; then wavefront 0 runs the three 256-element trees of
+// The scoring part (part 0).  All wavefronts first collect the candidate's slab -- lane t polls the K column partials of
+// bin t and sums them, others take the render marginal and the row sums -- into LDS; then wavefront 0 runs the three 256-element trees of
 // AddVectorPairwiseKernel (NMI.cu:295-339) side by side in DPP rows 0 (render marginal), 1 (frame marginal), 2 (joint
 // row sums), and the score.  (Fetched by wavefront 0 alone, 16 + 16K dependent loads per lane, this took 12 us.)
 template <int K>
-__device__ __forceinline__ void gather_slab(SplitLds<K> &lds, const SplitSlab *slab, int tid)
+__device__ __forceinline__ void gather_slab(SplitLds<K> &lds, const GridArgs &a, const SplitSlab *slab, int tid)
 {
     if (tid < kBins) {
         uint32_t c = 0;
+        unsigned long long v[K];
+        int tries = 0;
+        bool ok;
+        do {
+            ok = true;
 #pragma unroll
-        for (int j = 0; j < K; ++j) c += load_sc1(&slab->hw_part[j][tid]);
+            for (int j = 0; j < K; ++j) v[j] = load_granule(&slab->hw_part[j][tid]);
+#pragma unroll
+            for (int j = 0; j < K; ++j) ok = ok && (uint32_t)(v[j] >> 32) == a.epoch;
+            if (!ok) __builtin_amdgcn_s_sleep(8);
+        } while (!ok && ++tries < kMaxPolls);
+        if (!ok) raise_timeout(a);
+#pragma unroll
+        for (int j = 0; j < K; ++j) c += (uint32_t)v[j];
         lds.fin_warped[tid] = c;
-    } else if (tid < 2 * kBins) {
-        lds.fin_render[tid - kBins] = load_sc1(&slab->hist_render[tid - kBins]);
     } else if (tid < 3 * kBins) {
-        lds.fin_rows[tid - 2 * kBins] = load_sc1(&slab->row_sums[tid - 2 * kBins]);
+        const unsigned long long *src = tid < 2 * kBins ? &slab->hist_render[tid - kBins] : &slab->row_sums[tid - 2 * kBins];
+        unsigned long long v;
+        int tries = 0;
+        while ((uint32_t)((v = load_granule(src)) >> 32) != a.epoch && ++tries < kMaxPolls) __builtin_amdgcn_s_sleep(8);
+        if ((uint32_t)(v >> 32) != a.epoch) raise_timeout(a);
+        if (tid < 2 * kBins)
+            lds.fin_render[tid - kBins] = (uint32_t)v;
+        else
+            lds.fin_rows[tid - 2 * kBins] = __uint_as_float((uint32_t)v);
     }
 }
 
@@ -376,45 +413,60 @@ __device__ __forceinline__ void final_split(const SplitLds<K> &lds, const GridAr
 // Unit u of a launch = (candidate, part).  Candidates are taken in groups of 8, one per XCD (workgroups are dealt to the
 // XCDs round-robin: blocks b and b + 8 share one), and the K parts of a candidate are the blocks b, b + 8, ... of that
 // XCD, so they read the pair from one L2.  Placement is a speed matter only.
-// Merge of the pixel parts of one row part (P > 1).  Every workgroup stores its block of counters (sc1, 8 bytes per
-// store), all waves wait for their stores, one lane draws the row part's ticket.  Returns true in the workgroup that
-// arrived last, with the other P - 1 blocks added into its LDS counters; false elsewhere (counters cleared).
+// Merge of the pixel parts of one row part (P > 1).  Pixel ranges 1..P-1 send their counters to range 0 as granules of
+// two 24-bit counts + the 16-bit epoch tag (counts stay below 2^24: the host uses pixel parts only for frames of fewer
+// than 2^24 pixels) and are done; range 0 polls for them, adds them to its LDS counters and returns true.
 template <int K, int P>
-__device__ __forceinline__ bool merge_pixel_parts(SplitLds<K> &lds, const GridArgs &a, SplitSlab *slab, int cand, int part, int pix_part, int tid)
+__device__ __forceinline__ bool merge_pixel_parts(SplitLds<K> &lds, const GridArgs &a, int cand, int part, int pix_part, int tid)
 {
     constexpr int kRows = kBins / K;
-    constexpr int kPairs = kRows * kBins / 2;  // 8-byte units per block
-    unsigned long long *const mine = reinterpret_cast<unsigned long long *>(a.blocks) + ((size_t)(cand * K + part) * P + pix_part) * kPairs;
+    constexpr int kPairs = kRows * kBins / 2;   // granules per block: two counters each
+    constexpr int kPer = kPairs / kBlock;       // per lane
+    static_assert(kPairs % kBlock == 0, "a block is a whole number of granules per lane");
+    const unsigned long long tag = (unsigned long long)(a.epoch & 0xFFFFu) << 48;
     unsigned long long *const j2 = reinterpret_cast<unsigned long long *>(lds.joint);
-    for (int i = tid; i < kPairs; i += kBlock) __hip_atomic_store(&mine[i], j2[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned int arrived = __hip_atomic_fetch_add(&slab->ticket1[part], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool last = arrived == (unsigned int)(P - 1);
-        if (last) __hip_atomic_store(&slab->ticket1[part], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        lds.is_last = last ? 1u : 0u;
-    }
-    __syncthreads();
-    const bool last = lds.is_last != 0;
-    if (last) {
-        const unsigned long long *const base = reinterpret_cast<const unsigned long long *>(a.blocks) + (size_t)(cand * K + part) * P * kPairs;
-        for (int i = tid; i < kPairs; i += kBlock) {
-            unsigned long long acc = j2[i];
+    unsigned long long *const base = a.blocks + (size_t)(cand * K + part) * P * kPairs;
+    if (pix_part != 0) {
+        unsigned long long *const mine = base + (size_t)pix_part * kPairs;
 #pragma unroll
-            for (int q = 0; q < P; ++q) {
-                if (q == pix_part) continue;
-                const unsigned long long v = __hip_atomic_load(&base[(size_t)q * kPairs + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // two 32-bit counters per unit: add without a carry between them
-                acc = (((acc & 0xFFFFFFFFull) + (v & 0xFFFFFFFFull)) & 0xFFFFFFFFull) | (((acc >> 32) + (v >> 32)) << 32);
-            }
-            j2[i] = acc;
+        for (int e = 0; e < kPer; ++e) {
+            const int i = tid + e * kBlock;
+            const unsigned long long w = j2[i];
+            store_granule(&mine[i], (w & 0xFFFFFFull) | ((w >> 32) << 24) | tag);
+            j2[i] = 0ull;
         }
-    } else {
-        for (int i = tid; i < kPairs; i += kBlock) j2[i] = 0ull;
+        return false;
     }
-    __syncthreads();  // the merged counters are complete before decode; is_last is free for the second ticket
-    return last;
+    unsigned long long v[kPer][P - 1];
+    int tries = 0;
+    bool ok;
+    do {
+        ok = true;
+#pragma unroll
+        for (int e = 0; e < kPer; ++e)
+#pragma unroll
+            for (int q = 1; q < P; ++q) v[e][q - 1] = load_granule(&base[(size_t)q * kPairs + tid + e * kBlock]);
+#pragma unroll
+        for (int e = 0; e < kPer; ++e)
+#pragma unroll
+            for (int q = 1; q < P; ++q) ok = ok && (v[e][q - 1] >> 48) == (tag >> 48);
+        if (!ok) __builtin_amdgcn_s_sleep(2);
+    } while (!ok && ++tries < kMaxPolls);
+    if (!ok) raise_timeout(a);
+#pragma unroll
+    for (int e = 0; e < kPer; ++e) {
+        const int i = tid + e * kBlock;
+        unsigned long long acc = j2[i];
+        uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
+#pragma unroll
+        for (int q = 1; q < P; ++q) {
+            lo += (uint32_t)(v[e][q - 1] & 0xFFFFFFull);
+            hi += (uint32_t)((v[e][q - 1] >> 24) & 0xFFFFFFull);
+        }
+        j2[i] = (unsigned long long)lo | ((unsigned long long)hi << 32);
+    }
+    __syncthreads();  // the merged counters are complete before decode
+    return true;
 }
 
 template <int K, int P, bool FAST>
@@ -457,34 +509,21 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_split_kernel(GridArgs a
                                      use_bg != 0, pix_part, P);
         __syncthreads();
         stamp(2);
-        if (P > 1 && !merge_pixel_parts<K, P>(lds, a, slab, p, part, pix_part, tid)) continue;  // workgroup-uniform
+        if (P > 1 && !merge_pixel_parts<K, P>(lds, a, p, part, pix_part, tid)) continue;  // workgroup-uniform
         decode_split<K>(lds, a, slab, part, wave, lane);
         __syncthreads();
         stamp(3);
         if (tid < kBins) {
-            store_sc1(&slab->hw_part[part][tid], lds.hist_warped[tid]);
+            store_granule(&slab->hw_part[part][tid], granule32(lds.hist_warped[tid], a.epoch));
             lds.hist_warped[tid] = 0;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its slab stores have left before the ticket is drawn
-        __syncthreads();
-        if (tid == 0) {
-            const unsigned int arrived = __hip_atomic_fetch_add(&slab->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const bool last = arrived == (unsigned int)(K - 1);
-            if (last) __hip_atomic_store(&slab->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // all K arrived: next launch
-            lds.is_last = last ? 1u : 0u;
-        }
+        if (part != 0) continue;  // workgroup-uniform: only part 0 scores the candidate
+        gather_slab<K>(lds, a, slab, tid);
         __syncthreads();
         stamp(4);
-        if (lds.is_last) {  // workgroup-uniform
-            gather_slab<K>(lds, slab, tid);
-            __syncthreads();
-            if (wave == 0) {
-                final_split<K>(lds, a, lane, p, w, s, prev_key);
-                stamp(5);
-            }
-            // wavefront 0 writes is_last / fin_* again only after this final phase (tid 0 is one of its lanes, and the next
-            // unit's gather sits behind four more barriers); the other wavefronts meanwhile touch only the (already
-            // cleared) counters of the next unit.
+        if (wave == 0) {
+            final_split<K>(lds, a, lane, p, w, s, prev_key);
+            stamp(5);
         }
     }
     if (tid == 0 && !(a.phase_mask & 16)) publish_winner(a, prev_key);
@@ -509,7 +548,9 @@ hipError_t launch_split(const GridArgs &a, int parts, int pix_parts, int workgro
     if (!a.slabs || workgroups <= 0 || (workgroups & 7)) return hipErrorInvalidValue;
     if (pix_parts > 1 && (parts != 8 || !a.blocks)) return hipErrorInvalidValue;
     dim3 grid(workgroups), block(kBlock);
-    if (pix_parts == 4)
+    if (pix_parts == 8)
+        launch_split_k<8, 8>(a, grid, block, use_bg, stream);
+    else if (pix_parts == 4)
         launch_split_k<8, 4>(a, grid, block, use_bg, stream);
     else if (pix_parts == 2)
         launch_split_k<8, 2>(a, grid, block, use_bg, stream);
