@@ -259,6 +259,27 @@ int main()
                reps * n_r * n_w, w, h, dt / (reps * n_r * n_w) * 1e6, rate);
         printf("SHIM_EVALS_PER_S %.0f\n", rate);
         ok = ok && same && distinct;
+        // the same loop with the two extra lines a host may add: BeginBatch() before the warp loop, Flush() after it
+        std::vector<float> batched(n_r * n_w, -1.0f);
+        auto pass_batched = [&](std::vector<float> &outv) {
+            for (int r = 0; r < n_r; ++r) {
+                CUDAF::BeginBatch();
+                for (int v = 0; v < n_w; ++v)
+                    CUDAF::NMIWithCuda_noMask((cv::cuda::PtrStep<unsigned char> *)(d_img + (size_t)(n_r + v) * w * h), SUC, MATCHING_NMI, w, h,
+                                              &outv[r * n_w + v], 100u + r);
+                CUDAF::Flush();
+            }
+        };
+        pass_batched(batched);
+        const auto t1 = std::chrono::steady_clock::now();
+        for (int k = 0; k < reps; ++k) pass_batched(batched);
+        const double dtb = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+        bool same_b = true;
+        for (size_t k = 0; k < first.size(); ++k) same_b = same_b && first[k] == batched[k];
+        printf("shim call site with BeginBatch / Flush around the %d-warp loop: %.1f us per candidate = %.0f evals/s\n", n_w,
+               dtb / (reps * n_r * n_w) * 1e6, (double)reps * n_r * n_w / dtb);
+        printf("SHIM_BATCHED_EVALS_PER_S %.0f\n", (double)reps * n_r * n_w / dtb);
+        ok = ok && same_b;
         (void)hipFree(d_img);
     }
     (void)hipFree(d_rot);

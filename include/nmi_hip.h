@@ -91,6 +91,15 @@ int nmi_synchronize(nmi_ctx *ctx);
 int nmi_eval_pair(nmi_ctx *ctx, const uint8_t *render, const uint8_t *warped, float *h_score);
 
 /*
+ * A batch of independent candidates, each a (render, warped frame) pair of device images: the scores the reference would
+ * get from n consecutive calls of CUDAF::NMIWithCuda_noMask (kernel.cu:49-114), e.g. the Wn warps of the inner loop at
+ * src/Tracking.cc:1883-1894 against the render of the current outer iteration.  h_renders / h_warps are HOST arrays of n
+ * device pointers (the same pointer may appear many times); h_scores receives n floats.  Blocking.  One launch scores up
+ * to compute_units / 4 pairs (several workgroups per pair), larger batches take several launches.
+ */
+int nmi_eval_pairs(nmi_ctx *ctx, const uint8_t *const *h_renders, const uint8_t *const *h_warps, int32_t n, float *h_scores);
+
+/*
  * Same evaluation, additionally exporting the exact integer histograms and the three entropy sums
  * (the intermediate buffers d_JointHistogram / d_Histogram1 / d_Histogram2 and element 0 of
  * d_Entropy1 / d_Entropy2 / d_JointEntropyShort before the score is formed, kernel.cu:59-95).
@@ -287,17 +296,16 @@ int nmi_last_kernel_ms(nmi_ctx *ctx, float *h_ms);
                                   tile pass, at most 4194304 (default); 0 = every triangle is shaded by its own lane.
                                   Same image for every value (small values exercise the overflow path in tests). */
 #define NMI_OPT_SPLIT 7        /* small grids (nmi_eval_pair, collapsed search levels): K workgroups per candidate, each owning
-                                  256 / K rows of the joint histogram (no merge; bit-identical results).  -1 (default): the
-                                  largest K of 8 / 4 / 2 with candidates * K <= compute units, none for larger grids; 0: never;
+                                  256 / K rows of the joint histogram (no merge; bit-identical results).  -1 (default): K = 8
+                                  up to 32 candidates, 4 up to 64 (on 256 compute units), none for larger grids; 0: never;
                                   2 / 4 / 8: that K whenever the grid fits. */
 #define NMI_OPT_WAIT_MODE 8    /* how a blocking call waits for the posted result: 0 (default) spins on the pinned word
                                   (lowest latency, occupies the calling core for the search), 1 yields the core between
                                   polls (sched_yield; for hosts whose other threads need the core, e.g. ORB-SLAM2's
                                   LocalMapping / LoopClosing).  NMI_OPT_RESULT_PATH 0 sleeps in hipStreamSynchronize instead. */
-#define NMI_OPT_SPLIT_PIXELS 10 /* with 8 row parts, additionally cut the pixels of each pair into 2, 4 or 8 ranges (one workgroup
-                                  per row part and range, merged per row part: nmi_eval_pair = 64 workgroups).  -1 (default):
-                                  the largest of 8 / 4 / 2 with candidates * 8 * ranges <= compute units; 1: never; 2 / 4 / 8:
-                                  that many when it fits. */
+#define NMI_OPT_SPLIT_PIXELS 10 /* with 8 row parts, additionally cut the pixels of each pair into 2 or 4 ranges (one workgroup per
+                                  row part and range, merged per row part: nmi_eval_pair = 32 workgroups).  -1 (default): 4 / 2
+                                  when the launch then still fits the compute units; 1: never; 2 / 4: that many when it fits. */
 #define NMI_OPT_STAMPS 9       /* profiling tools only: value = device pointer to uint64 [workgroups][8]; workgroups of the
                                   split kernel store wall-clock stamps (100 MHz) at their phase boundaries there; 0 = off */
 int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value);

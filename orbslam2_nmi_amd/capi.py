@@ -22,7 +22,7 @@ ERR_NOT_READY = -4
 
 # Every symbol include/nmi_hip.h declares; tests check that the library exports all of them.
 EXPORTED_SYMBOLS = (
-    "nmi_params_default", "nmi_create", "nmi_destroy", "nmi_set_stream", "nmi_synchronize", "nmi_eval_pair", "nmi_eval_pair_debug",
+    "nmi_params_default", "nmi_create", "nmi_destroy", "nmi_set_stream", "nmi_synchronize", "nmi_eval_pair", "nmi_eval_pairs", "nmi_eval_pair_debug",
     "nmi_search_grid", "nmi_search_grid_shard", "nmi_search_grid_block", "nmi_warp_homographies", "nmi_warp_stack", "nmi_render_mvp", "nmi_render_points", "nmi_level_create", "nmi_level_create_mesh", "nmi_level_run", "nmi_level_copy_outputs", "nmi_level_destroy", "nmi_texture_create",
     "nmi_texture_destroy", "nmi_render_mesh", "nmi_stream_create", "nmi_stream_destroy",
     "nmi_stream_submit", "nmi_stream_wait", "nmi_stream_keep_ratings", "nmi_stream_copy_ratings", "nmi_key_pack", "nmi_key_unpack", "nmi_search_grid_rccl", "nmi_search_grid_block_rccl",
@@ -76,6 +76,7 @@ def load_library(build_if_missing=False):
     lib.nmi_set_stream.argtypes = [vp, vp]
     lib.nmi_synchronize.argtypes = [vp]
     lib.nmi_eval_pair.argtypes = [vp, vp, vp, f32p]
+    lib.nmi_eval_pairs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i32, f32p]
     lib.nmi_eval_pair_debug.argtypes = [vp, vp, vp, f32p, vp, vp, vp, vp]
     lib.nmi_search_grid.argtypes = [vp, vp, i32, vp, i32, vp, i64p, f32p]
     lib.nmi_search_grid_shard.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp, u64p]
@@ -288,6 +289,17 @@ class NmiContext:
         self._order_after_torch()
         self._check(self._lib.nmi_eval_pair(self._h, r.data_ptr(), w.data_ptr(), C.byref(out)), "nmi_eval_pair")
         return np.float32(out.value)
+
+    def eval_pairs(self, renders, warps):
+        """n independent (render, warped) pairs (lists of device images) in as few launches as possible -> float32 [n]."""
+        assert len(renders) == len(warps)
+        n = len(renders)
+        rp = (C.c_void_p * max(n, 1))(*[self._img(r, "render").data_ptr() for r in renders])
+        wp = (C.c_void_p * max(n, 1))(*[self._img(w, "warped").data_ptr() for w in warps])
+        out = np.zeros(n, np.float32)
+        self._order_after_torch()
+        self._check(self._lib.nmi_eval_pairs(self._h, rp, wp, n, out.ctypes.data_as(C.POINTER(C.c_float))), "nmi_eval_pairs")
+        return out
 
     def eval_pair_debug(self, render, warped):
         """-> (score, joint[256,256] u32 (render x warped), hist_render[256], hist_warped[256], sums[3]) as numpy."""

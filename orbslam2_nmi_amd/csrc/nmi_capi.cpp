@@ -81,13 +81,12 @@ static void choose_split(const nmi_ctx *ctx, int64_t total, int cap, int *parts,
     *parts = 0;
     *pix_parts = 1;
     if (ctx->hist_variant != 3 || ctx->split_mode == 0 || total <= 0 || total > cap) return;
-    const int cap8 = (cap + 7) & ~7;
-    auto fits = [&](int k, int p) { return total * k * p <= cap && nmi::split_workgroups((int)total, k * p) <= cap8; };
+    auto fits = [&](int k, int p) { return nmi::split_workgroups((int)total, k * p) <= cap; };
     if (ctx->split_mode > 0) {
         if (!fits(ctx->split_mode, 1)) return;
         *parts = ctx->split_mode;
     } else {
-        for (int k = 8; k >= 2 && !*parts; k >>= 1)
+        for (int k = 8; k >= 4 && !*parts; k >>= 1)  // 2 row parts are available on request only: measured no faster than none
             if (fits(k, 1)) *parts = k;
         if (!*parts) return;
     }
@@ -95,7 +94,7 @@ static void choose_split(const nmi_ctx *ctx, int64_t total, int cap, int *parts,
         if (ctx->split_pixels > 1) {
             if (fits(8, ctx->split_pixels)) *pix_parts = ctx->split_pixels;
         } else {
-            for (int p = 8; p >= 2 && *pix_parts == 1; p >>= 1)
+            for (int p = 4; p >= 2 && *pix_parts == 1; p >>= 1)
                 if (fits(8, p)) *pix_parts = p;
         }
     }
@@ -162,6 +161,13 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     a.S_total = S_total;
     a.w_offset = w_offset;
     nmi::set_geometry(a, p.width, p.height, render_stack, warp_stack, p.render_bottom_up != 0);
+    if (ctx->pair_renders) {  // nmi_eval_pairs: per-pair pointers; the 16-byte path needs every one of them aligned
+        a.pair_renders = ctx->pair_renders;
+        a.pair_warps = ctx->pair_warps;
+        uintptr_t bits = 0;
+        for (int i = 0; i < S_local; ++i) bits |= (uintptr_t)ctx->pair_renders_host[i] | (uintptr_t)ctx->pair_warps_host[i];
+        if (bits % 16) nmi::set_geometry(a, p.width, p.height, (const void *)1, (const void *)1, p.render_bottom_up != 0);
+    }
     a.shift = ctx->shift;
     a.mode = p.mode;
     a.table = ctx->table;
@@ -485,6 +491,8 @@ int nmi_destroy(nmi_ctx *ctx)
     if (ctx->d_reduced_key) (void)hipFree(ctx->d_reduced_key);
     if (ctx->score_mailbox) (void)hipHostFree(ctx->score_mailbox);
     if (ctx->d_slabs) (void)hipFree(ctx->d_slabs);
+    if (ctx->h_pair_table) (void)hipHostFree(ctx->h_pair_table);
+    if (ctx->d_pair_scores) (void)hipFree(ctx->d_pair_scores);
     if (ctx->d_blocks) (void)hipFree(ctx->d_blocks);
     if (ctx->h_split_error) (void)hipHostFree(ctx->h_split_error);
     if (ctx->d_keys) (void)hipFree(ctx->d_keys);
@@ -546,7 +554,7 @@ int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value)
         ctx->split_mode = (int)value;
         return NMI_OK;
     case NMI_OPT_SPLIT_PIXELS:
-        if (value != -1 && value != 1 && value != 2 && value != 4 && value != 8) return NMI_ERR_INVALID_ARGUMENT;
+        if (value != -1 && value != 1 && value != 2 && value != 4) return NMI_ERR_INVALID_ARGUMENT;
         ctx->split_pixels = (int)value;
         return NMI_OK;
     case NMI_OPT_STAMPS:
@@ -709,6 +717,63 @@ int nmi_eval_pair_debug(nmi_ctx *ctx, const uint8_t *render, const uint8_t *warp
     NMI_HIP_TRY(ctx, hipMemcpyAsync(h_score, ctx->d_pair_rating, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (split_timed_out(ctx)) return nmi_eval_pair_debug(ctx, render, warped, h_score, d_joint, d_hist_render, d_hist_warped, d_sums);
+    return NMI_OK;
+}
+
+int nmi_eval_pairs(nmi_ctx *ctx, const uint8_t *const *h_renders, const uint8_t *const *h_warps, int32_t n, float *h_scores)
+{
+    if (!ctx || n < 0 || (n > 0 && (!h_renders || !h_warps || !h_scores))) return NMI_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < n; ++i)
+        if (!h_renders[i] || !h_warps[i]) return NMI_ERR_INVALID_ARGUMENT;
+    ctx->detail.clear();
+    if (n == 0) return NMI_OK;
+    DeviceGuard guard(ctx->device);
+    if (ctx->hist_variant != 3 || ctx->split_mode == 0) {  // split forms unavailable: one pair at a time
+        for (int i = 0; i < n; ++i) {
+            const int rc = nmi_eval_pair(ctx, h_renders[i], h_warps[i], &h_scores[i]);
+            if (rc != NMI_OK) return rc;
+        }
+        return NMI_OK;
+    }
+    // pointer tables (pinned, device-mapped) and the scores (device), grown on demand
+    if (n > ctx->pairs_cap) {
+        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->h_pair_table) NMI_HIP_TRY(ctx, hipHostFree(ctx->h_pair_table));
+        if (ctx->d_pair_scores) NMI_HIP_TRY(ctx, hipFree(ctx->d_pair_scores));
+        ctx->h_pair_table = nullptr;
+        ctx->d_pair_scores = nullptr;
+        ctx->pairs_cap = 0;
+        const int cap = n > 256 ? n : 256;
+        NMI_HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_pair_table, (size_t)cap * 2 * sizeof(void *), hipHostMallocMapped | hipHostMallocCoherent));
+        NMI_HIP_TRY(ctx, hipHostGetDevicePointer((void **)&ctx->d_pair_table, ctx->h_pair_table, 0));
+        NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_pair_scores, (size_t)cap * sizeof(float)));
+        ctx->pairs_cap = cap;
+    } else {
+        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // an earlier batch may still be reading the tables
+    }
+    for (int i = 0; i < n; ++i) {
+        ctx->h_pair_table[i] = h_renders[i];
+        ctx->h_pair_table[ctx->pairs_cap + i] = h_warps[i];
+    }
+    // launches of at most compute_units / 4 pairs (4 row parts each); small batches get more parts per pair
+    const int min_parts = ctx->split_mode > 0 ? ctx->split_mode : 4;
+    const int cus = ctx->workgroups > 0 && ctx->workgroups < ctx->compute_units ? ctx->workgroups : ctx->compute_units;
+    const int per_launch = cus / min_parts > 0 ? ((cus / min_parts) & ~7) > 0 ? (cus / min_parts) & ~7 : 1 : 1;
+    for (int off = 0; off < n; off += per_launch) {
+        const int m = n - off < per_launch ? n - off : per_launch;
+        ctx->pair_renders = ctx->d_pair_table + off;
+        ctx->pair_warps = ctx->d_pair_table + ctx->pairs_cap + off;
+        ctx->pair_renders_host = h_renders + off;
+        ctx->pair_warps_host = h_warps + off;
+        const int rc = enqueue_grid(ctx, h_renders[off], m, 0, m, h_warps[off], 1, ctx->d_pair_scores + off, nullptr, false, nullptr,
+                                    nullptr, nullptr, nullptr);
+        ctx->pair_renders = ctx->pair_warps = nullptr;
+        if (rc != NMI_OK) return rc;
+        if (!ctx->last_parts) return NMI_ERR_UNSUPPORTED;  // cannot happen: m * 2 <= compute units
+    }
+    NMI_HIP_TRY(ctx, hipMemcpyAsync(h_scores, ctx->d_pair_scores, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (split_timed_out(ctx)) return nmi_eval_pairs(ctx, h_renders, h_warps, n, h_scores);  // now one pair at a time
     return NMI_OK;
 }
 

@@ -67,6 +67,12 @@ struct nmi_ctx {
     uint32_t split_epoch = 0;             // tag of the latest split launch
     uint32_t *h_split_error = nullptr, *d_split_error = nullptr;  // pinned: raised by the kernel when a hand-off timed out
     size_t blocks_bytes = 0;
+    // nmi_eval_pairs: pointer tables [2][pairs_cap] in pinned host memory (renders, then warps) + device scores
+    const uint8_t **h_pair_table = nullptr, **d_pair_table = nullptr;
+    float *d_pair_scores = nullptr;
+    int pairs_cap = 0;
+    const uint8_t *const *pair_renders = nullptr, *const *pair_warps = nullptr;            // device views for the launch being enqueued
+    const uint8_t *const *pair_renders_host = nullptr, *const *pair_warps_host = nullptr;  // the caller's arrays (alignment check)
     int split_pixels = -1;                // NMI_OPT_SPLIT_PIXELS: -1 automatic, 1 / 2 / 4
     unsigned long long *dbg_stamps = nullptr;  // NMI_OPT_STAMPS
     int split_mode = -1;                  // NMI_OPT_SPLIT: -1 automatic, 0 never, 2 / 4 / 8 parts whenever the grid fits

@@ -19,6 +19,10 @@ struct Mailbox {
 struct GridArgs {
     const uint8_t *render_stack;  // [S_local][H][W]
     const uint8_t *warp_stack;    // [Wn][H][W]
+    // nmi_eval_pairs (split kernel only): candidate p scores (pair_renders[p], pair_warps[p]) instead of stack entries;
+    // the tables live in pinned host memory that the device reads directly.  nullptr = stacks.
+    const uint8_t *const *pair_renders;
+    const uint8_t *const *pair_warps;
     int S_local, Wn;
     int s_offset, S_total;        // position of this shard in the global grid
     int w_offset;                 // first warp of this shard in the global grid (0 unless the warp axis is sharded)
@@ -81,10 +85,10 @@ struct SplitSlab {
     unsigned long long hist_render[256];  // {render marginal count = row sum of the counts, epoch}, each row by its owner
     unsigned long long hw_part[8][256];   // {frame marginal: column sum over the rows of one part, epoch}
 };
-// pix_parts (1, 2, 4 or 8; > 1 only with parts = 8): the pixels of the pair are additionally cut into that many ranges, one
+// pix_parts (1, 2 or 4; > 1 only with parts = 8): the pixels of the pair are additionally cut into that many ranges, one
 // workgroup per (row part, pixel range); the workgroups of a row part merge their counters through `blocks`.
 hipError_t launch_split(const GridArgs &a, int parts, int pix_parts, int workgroups, bool use_bg, hipStream_t stream);
-int split_workgroups(int candidates, int parts_times_pix_parts);  // grid size that keeps a candidate's workgroups on one XCD
+__host__ __device__ int split_workgroups(int candidates, int parts_times_pix_parts);  // grid size of a split launch (one unit per workgroup)
 inline size_t split_block_bytes_per_candidate(int pix_parts) { return (size_t)pix_parts * 256 * 128 * sizeof(unsigned long long); }
 int grid_kernel_lds_bytes();
 size_t grid_kernel_scratch_bytes(int workgroups);

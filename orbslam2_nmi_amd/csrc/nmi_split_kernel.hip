@@ -180,6 +180,25 @@ __device__ __forceinline__ void add_chunk_careful(uint32_t *joint, const uint4 &
     if (issue) add_pixel_split<K>(joint, rb, wb, part, true, 0, weight);
 }
 
+// 16-byte chunk c of the frame / of the render row that meets it (NMI.cu:82: row y of the frame meets row H-1-y of a
+// bottom-up render; see histogram_phase in nmi_kernels.hip).  Indices are clamped to the last chunk: loads are unconditional.
+__device__ __forceinline__ uint4 load_frame_chunk(const uint8_t *__restrict__ warped, int c, int last)
+{
+    return *reinterpret_cast<const uint4 *>(warped + ((uint32_t)min(c, last) << 4));
+}
+__device__ __forceinline__ uint4 load_render_chunk(const GridArgs &a, const uint8_t *__restrict__ render, int c, int last)
+{
+    c = min(c, last);
+    const int y = (int)__umulhi((uint32_t)c, a.cpr_magic);
+    return *reinterpret_cast<const uint4 *>(render + ((uint32_t)(__mul24(y, a.flip_row) + c + a.flip_base) << 4));
+}
+__device__ __forceinline__ void split_range(int all_chunks, int pix_part, int pix_parts, int &first, int &end)
+{
+    const int per_part = (all_chunks + pix_parts - 1) / pix_parts;
+    first = min(pix_part * per_part, all_chunks);
+    end = min(first + per_part, all_chunks);
+}
+
 // Histogram phase of one part: histogram256Kernel's pixel loop (NMI.cu:79-87) over ALL pixels of the pair, counting
 // only the pixels whose render intensity belongs to this part's rows.
 template <int K, bool FAST>
@@ -193,16 +212,10 @@ __device__ __forceinline__ void histogram_split(uint32_t *joint, const GridArgs 
         const int all_chunks = a.npix >> 4;
         const int last = all_chunks - 1;
         // this workgroup's pixel range, in 16-pixel chunks: [first, nchunks)
-        const int per_part = (all_chunks + pix_parts - 1) / pix_parts;
-        const int first = min(pix_part * per_part, all_chunks);
-        const int nchunks = min(first + per_part, all_chunks);
-        auto ldw = [&](int c) { return *reinterpret_cast<const uint4 *>(warped + ((uint32_t)min(c, last) << 4)); };
-        // NMI.cu:82: row y of the frame meets row H-1-y of a bottom-up render (see histogram_phase in nmi_kernels.hip)
-        auto ldr = [&](int c) {
-            c = min(c, last);
-            const int y = (int)__umulhi((uint32_t)c, a.cpr_magic);
-            return *reinterpret_cast<const uint4 *>(render + ((uint32_t)(__mul24(y, a.flip_row) + c + a.flip_base) << 4));
-        };
+        int first, nchunks;
+        split_range(all_chunks, pix_part, pix_parts, first, nchunks);
+        auto ldw = [&](int c) { return load_frame_chunk(warped, c, last); };
+        auto ldr = [&](int c) { return load_render_chunk(a, render, c, last); };
         if (FAST) {
             // Software pipeline with two named register sets of TWO chunk pairs each (64 B per lane and set): while one
             // set's 32 pixels are added the other set's four loads are in flight -- a part has to pull the whole pair
@@ -410,9 +423,19 @@ __device__ __forceinline__ void final_split(const SplitLds<K> &lds, const GridAr
 
 }  // namespace
 
-// Unit u of a launch = (candidate, part).  Candidates are taken in groups of 8, one per XCD (workgroups are dealt to the
-// XCDs round-robin: blocks b and b + 8 share one), and the K parts of a candidate are the blocks b, b + 8, ... of that
-// XCD, so they read the pair from one L2.  Placement is a speed matter only.
+// Unit u of a launch = (candidate, row part, pixel range).  Workgroups are dealt to the 8 XCDs round-robin (blocks b and
+// b + 8 share one).  Candidates are taken in groups of 8, one per XCD, and all workgroups of a candidate are blocks
+// b, b + 8, ... of that XCD: they read the pair from one L2 and their hand-offs stay inside one XCD.  (Measured: one
+// pair's 32 workgroups spread over the 8 XCDs start 1.5 us apart and finish 1-6 us later than on one XCD, 64 workgroups
+// -- 8 pixel ranges -- later still; with fewer than 8 candidates the other XCDs' workgroups simply exit.)  Placement is
+// a speed matter only.
+__device__ __forceinline__ void split_unit(int u, int kp, int &cand, int &sub)
+{
+    const int x = u & 7, t = u >> 3;
+    sub = t % kp;
+    cand = (t / kp) * 8 + x;
+}
+
 // Merge of the pixel parts of one row part (P > 1).  Pixel ranges 1..P-1 send their counters to range 0 as granules of
 // two 24-bit counts + the 16-bit epoch tag (counts stay below 2^24: the host uses pixel parts only for frames of fewer
 // than 2^24 pixels) and are done; range 0 polls for them, adds them to its LDS counters and returns true.
@@ -483,6 +506,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_split_kernel(GridArgs a
     stamp(0);
     const long long clk0 = a.dbg_stamps ? clock64() : 0;  // shader-clock counter: with the wall-clock stamps it gives the clock held
     if (blockIdx.x == 0 && tid == 0 && a.reset_key) *a.reset_key = 0ull;  // next launch's slot; idle during this one
+    const int total = a.S_local * a.Wn;
     {
         uint4 *j4 = reinterpret_cast<uint4 *>(lds.joint);
         const uint4 z = {0, 0, 0, 0};
@@ -493,20 +517,20 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_split_kernel(GridArgs a
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds.joint != 0u) __builtin_trap();
     __syncthreads();
 
-    const int total = a.S_local * a.Wn;
-    const int units = ((total + 7) >> 3) * 8 * K * P;
+    const int units = split_workgroups(total, K * P);
     unsigned long long prev_key = 0;
     for (int u = blockIdx.x; u < units; u += gridDim.x) {
-        const int x = u & 7, t = u >> 3;
-        const int sub = t % (K * P), part = sub % K, pix_part = sub / K, p = (t / (K * P)) * 8 + x;
+        int p, sub;
+        split_unit(u, K * P, p, sub);
+        const int part = sub % K, pix_part = sub / K;
         if (p >= total) continue;  // workgroup-uniform
         const int w = p / a.S_local, s = p - w * a.S_local;
         SplitSlab *slab = a.slabs + p;
 
         stamp(1);
         if (a.phase_mask & 1)
-            histogram_split<K, FAST>(lds.joint, a, a.render_stack + (size_t)s * a.npix, a.warp_stack + (size_t)w * a.npix, tid, part,
-                                     use_bg != 0, pix_part, P);
+            histogram_split<K, FAST>(lds.joint, a, a.pair_renders ? a.pair_renders[p] : a.render_stack + (size_t)s * a.npix,
+                                     a.pair_warps ? a.pair_warps[p] : a.warp_stack + (size_t)w * a.npix, tid, part, use_bg != 0, pix_part, P);
         __syncthreads();
         stamp(2);
         if (P > 1 && !merge_pixel_parts<K, P>(lds, a, p, part, pix_part, tid)) continue;  // workgroup-uniform
@@ -531,7 +555,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_split_kernel(GridArgs a
     if (a.dbg_stamps && tid == 0) a.dbg_stamps[blockIdx.x * 8 + 7] = (unsigned long long)(clock64() - clk0);
 }
 
-int split_workgroups(int candidates, int parts_times_pix_parts) { return ((candidates + 7) / 8) * 8 * parts_times_pix_parts; }
+__host__ __device__ int split_workgroups(int candidates, int parts_times_pix_parts) { return ((candidates + 7) / 8) * 8 * parts_times_pix_parts; }
 
 template <int K, int P>
 static void launch_split_k(const GridArgs &a, dim3 grid, dim3 block, bool use_bg, hipStream_t stream)
@@ -548,9 +572,7 @@ hipError_t launch_split(const GridArgs &a, int parts, int pix_parts, int workgro
     if (!a.slabs || workgroups <= 0 || (workgroups & 7)) return hipErrorInvalidValue;
     if (pix_parts > 1 && (parts != 8 || !a.blocks)) return hipErrorInvalidValue;
     dim3 grid(workgroups), block(kBlock);
-    if (pix_parts == 8)
-        launch_split_k<8, 8>(a, grid, block, use_bg, stream);
-    else if (pix_parts == 4)
+    if (pix_parts == 4)
         launch_split_k<8, 4>(a, grid, block, use_bg, stream);
     else if (pix_parts == 2)
         launch_split_k<8, 2>(a, grid, block, use_bg, stream);

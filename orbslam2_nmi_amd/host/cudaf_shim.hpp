@@ -19,6 +19,7 @@
 
 #include <map>
 #include <utility>
+#include <vector>
 
 #include "nmi_config.hpp"
 #include "nmi_hip.h"
@@ -36,6 +37,12 @@ namespace detail {
 struct State {
     std::map<unsigned int, const uint8_t *> renders;          // GL texture name -> linear device copy
     std::map<std::pair<int, int>, nmi_ctx *> contexts;        // one persistent workspace per frame size
+    // BeginBatch() .. Flush(): calls are recorded here and scored together
+    bool batching = false;
+    int batch_w = 0, batch_h = 0;
+    std::vector<const uint8_t *> batch_renders, batch_warps;
+    std::vector<float *> batch_out;
+    std::vector<float> batch_scores;
     // No destructor on purpose: this object dies during static destruction, possibly after the HIP runtime has shut
     // down; call CUDAF::Shutdown() to release the workspaces earlier (the reference frees per call, kernel.cu:103-113).
 };
@@ -81,12 +88,53 @@ inline void Shutdown()
     detail::state().renders.clear();
 }
 
+// Optional batching for hosts that can add two lines around the inner loop of Tracking::RelocalizeWithNMI
+// (src/Tracking.cc:1883-1894):
+//     CUDAF::BeginBatch();
+//     for (wX..) for (wY..) for (wZ..) CUDAF::NMIWithCuda_noMask(..., &rating[wZ][wY][wX][sZ][sY][sX], renderedTexture);
+//     CUDAF::Flush();        // before the next renderToTextureOnGPU overwrites the texture
+// Between the two, NMIWithCuda_noMask only records its arguments; Flush scores all recorded candidates with one
+// nmi_eval_pairs call (one launch for the 27 warps of a default grid) and writes every *NMI.  Same values as unbatched.
+inline void BeginBatch()
+{
+    detail::State &st = detail::state();
+    st.batching = true;
+    st.batch_renders.clear();
+    st.batch_warps.clear();
+    st.batch_out.clear();
+}
+inline void Flush()
+{
+    detail::State &st = detail::state();
+    st.batching = false;
+    const int n = (int)st.batch_out.size();
+    if (n == 0) return;
+    nmi_ctx *ctx = detail::context(st.batch_w, st.batch_h);
+    st.batch_scores.resize((size_t)n);
+    const int rc = nmi_eval_pairs(ctx, st.batch_renders.data(), st.batch_warps.data(), n, st.batch_scores.data());
+    if (rc != NMI_OK) detail::die(rc, "nmi_eval_pairs", ctx);
+    for (int i = 0; i < n; ++i) *st.batch_out[(size_t)i] = st.batch_scores[(size_t)i];
+    st.batch_renders.clear();
+    st.batch_warps.clear();
+    st.batch_out.clear();
+}
+
 // Identical signature to kernel.cuh:37.
 inline void NMIWithCuda_noMask(cv::cuda::PtrStep<unsigned char> *d_Warped, int /*NMI_mode*/, int /*MatchingMode*/, int width,
                                int height, float *NMI, unsigned int syntGL)
 {
     auto it = detail::state().renders.find(syntGL);
     if (it == detail::state().renders.end()) detail::die(NMI_ERR_INVALID_ARGUMENT, "lookup of the render buffer", nullptr);
+    detail::State &st = detail::state();
+    if (st.batching) {
+        if (!st.batch_out.empty() && (width != st.batch_w || height != st.batch_h)) Flush(), st.batching = true;  // one frame size per batch
+        st.batch_w = width;
+        st.batch_h = height;
+        st.batch_renders.push_back(it->second);
+        st.batch_warps.push_back(reinterpret_cast<const uint8_t *>(d_Warped));
+        st.batch_out.push_back(NMI);
+        return;
+    }
     nmi_ctx *ctx = detail::context(width, height);
     const int rc = nmi_eval_pair(ctx, it->second, reinterpret_cast<const uint8_t *>(d_Warped), NMI);
     if (rc != NMI_OK) detail::die(rc, "nmi_eval_pair", ctx);

@@ -36,7 +36,7 @@ def dev(a):
 # leaves compute units idle), 0 the one-workgroup-per-candidate kernel only, 8 / 4 / 2 forced.  Tests that take this
 # fixture run once per mode; results must be identical bit for bit.
 # A tuple (8, P) additionally forces P pixel ranges per row part (NMI_OPT_SPLIT_PIXELS); plain 8 / 4 / 2 run without them.
-@pytest.fixture(params=[-1, 0, (8, 8), (8, 4), (8, 2), 8, 4, 2],
+@pytest.fixture(params=[-1, 0, (8, 4), (8, 2), 8, 4, 2],
                 ids=lambda m: {-1: "auto", 0: "nosplit"}.get(m, f"split{m[0]}x{m[1]}" if isinstance(m, tuple) else f"split{m}"))
 def split_mode(request, nmi):
     from orbslam2_nmi_amd import capi
@@ -549,6 +549,40 @@ def test_wait_modes_and_result_paths_agree(nmi):
         assert ctx.info()["workgroups_per_launch"] == ctx.info()["compute_units"]
         ctx.set_option(ctx.OPT_WORKGROUPS, 40)
         assert ctx.info()["workgroups_per_launch"] == 40 and ctx.search_grid(rs, ws) == ref
+
+
+def test_eval_pairs_equals_single_calls(nmi):
+    """nmi_eval_pairs (the batch form behind CUDAF::BeginBatch / Flush): arbitrary (render, warp) pairs, repeated
+    pointers, more pairs than one launch holds, an unaligned image (generic pixel path) -- every score equals the
+    single-pair call's, bit for bit, and the oracle's."""
+    from oracle import binding as oc
+    rng = np.random.default_rng(17)
+    w, h = 160, 120
+    imgs = rng.integers(0, 256, (12, h, w), dtype=np.uint8)
+    imgs[3] = np.clip(imgs[0].astype(int) + rng.integers(-20, 20, (h, w)), 0, 255)
+    imgs[7][: h // 2] = 255
+    d = dev(imgs)
+    with nmi.NmiContext(w, h) as ctx:
+        assert ctx.eval_pairs([], []).shape == (0,)
+        single = {(r, v): ctx.eval_pair(d[r], d[v]) for r in range(12) for v in range(12)}
+        for n in (1, 2, 9, 27, 40, 144, 300):
+            pairs = [(int(rng.integers(12)), int(rng.integers(12))) for _ in range(n)]
+            if n == 27:
+                pairs = [(5, v % 12) for v in range(27)]       # one render against many warps: the reference's inner loop
+            got = ctx.eval_pairs([d[r] for r, _ in pairs], [d[v] for _, v in pairs])
+            assert [np.float32(x) for x in got] == [single[p] for p in pairs], n
+        with oc.rounded():
+            assert ctx.eval_pairs([d[0]], [d[3]])[0] == oc.eval_pair(imgs[0], imgs[3])
+        # an image that does not start on a 16-byte boundary: the batch falls back to the byte-wise pixel loop
+        flat = torch.zeros(h * w + 16, dtype=torch.uint8, device="cuda")
+        odd = flat[3:3 + h * w].view(h, w)
+        odd.copy_(d[4])
+        got = ctx.eval_pairs([odd, d[1]], [d[2], odd])
+        assert (np.float32(got[0]), np.float32(got[1])) == (single[(4, 2)], single[(1, 4)])
+        for mode in (8, 4, 2, 0):   # forced part counts, and the split forms switched off (one pair per launch)
+            ctx.set_option(ctx.OPT_SPLIT, mode)
+            got = ctx.eval_pairs([d[r] for r in range(12)], [d[(r * 5) % 12] for r in range(12)])
+            assert [np.float32(x) for x in got] == [single[(r, (r * 5) % 12)] for r in range(12)], mode
 
 
 def test_invalid_arguments_fail_loudly(nmi):
