@@ -81,7 +81,7 @@ static void choose_split(const nmi_ctx *ctx, int64_t total, int cap, int *parts,
     *parts = 0;
     *pix_parts = 1;
     if (ctx->hist_variant != 3 || ctx->split_mode == 0 || total <= 0 || total > cap) return;
-    auto fits = [&](int k, int p) { return nmi::split_workgroups((int)total, k * p) <= cap; };
+    auto fits = [&](int k, int p) { return nmi::split_workgroups((int)total, k, p) <= cap; };
     if (ctx->split_mode > 0) {
         if (!fits(ctx->split_mode, 1)) return;
         *parts = ctx->split_mode;
@@ -226,7 +226,7 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
         a.slabs = ctx->d_slabs;
         a.blocks = ctx->d_blocks;
         a.split_error = ctx->d_split_error;
-        workgroups = nmi::split_workgroups((int)total, parts * pix_parts);
+        workgroups = nmi::split_workgroups((int)total, parts, pix_parts);
     } else if (ctx->xcd_tiling && total <= (1ll << 24)) {  // 4 B per candidate
         const int orc = ensure_order(ctx, S_local, Wn, &a.order);
         if (orc != NMI_OK) return orc;
@@ -565,7 +565,7 @@ int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value)
         ctx->wait_mode = (int)value;
         return NMI_OK;
     case NMI_OPT_PHASE_MASK:
-        if (value < 0 || value > 255) return NMI_ERR_INVALID_ARGUMENT;
+        if (value < 0 || value > 511) return NMI_ERR_INVALID_ARGUMENT;
         ctx->phase_mask = (int)value;
         return NMI_OK;
     case NMI_OPT_XCD_TILING:

@@ -88,7 +88,7 @@ struct SplitSlab {
 // pix_parts (1, 2 or 4; > 1 only with parts = 8): the pixels of the pair are additionally cut into that many ranges, one
 // workgroup per (row part, pixel range); the workgroups of a row part merge their counters through `blocks`.
 hipError_t launch_split(const GridArgs &a, int parts, int pix_parts, int workgroups, bool use_bg, hipStream_t stream);
-__host__ __device__ int split_workgroups(int candidates, int parts_times_pix_parts);  // grid size of a split launch (one unit per workgroup)
+__host__ __device__ int split_workgroups(int candidates, int parts, int pix_parts);  // grid size of a split launch (one unit per workgroup)
 inline size_t split_block_bytes_per_candidate(int pix_parts) { return (size_t)pix_parts * 256 * 128 * sizeof(unsigned long long); }
 int grid_kernel_lds_bytes();
 size_t grid_kernel_scratch_bytes(int workgroups);

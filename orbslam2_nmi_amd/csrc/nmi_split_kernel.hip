@@ -424,16 +424,29 @@ __device__ __forceinline__ void final_split(const SplitLds<K> &lds, const GridAr
 }  // namespace
 
 // Unit u of a launch = (candidate, row part, pixel range).  Workgroups are dealt to the 8 XCDs round-robin (blocks b and
-// b + 8 share one).  Candidates are taken in groups of 8, one per XCD, and all workgroups of a candidate are blocks
-// b, b + 8, ... of that XCD: they read the pair from one L2 and their hand-offs stay inside one XCD.  (Measured: one
-// pair's 32 workgroups spread over the 8 XCDs start 1.5 us apart and finish 1-6 us later than on one XCD, 64 workgroups
-// -- 8 pixel ranges -- later still; with fewer than 8 candidates the other XCDs' workgroups simply exit.)  Placement is
-// a speed matter only.
-__device__ __forceinline__ void split_unit(int u, int kp, int &cand, int &sub)
+// b + 8 share one), and hand-offs inside one XCD are the fast ones.
+//   8 or more candidates: taken in groups of 8, one per XCD; all workgroups of a candidate are blocks b, b + 8, ... of
+//     that XCD, so they read the pair from one L2 and both hand-off stages stay inside the XCD (the grid is padded to a
+//     multiple of 8 candidates; surplus workgroups exit).
+//   fewer than 8 candidates with 8 row parts: the grid is exactly candidates x 8 x P workgroups and ROW PART j lives on
+//     XCD j: the pixel ranges of a row part (the 32 KiB merges) share an XCD, only the small slab crosses XCDs, and
+//     every XCD's L2 serves a share of the pixel stream.  (One pair: 32 workgroups instead of 256 dispatched, 1.2 us
+//     less per blocking call; the same 32 workgroups dealt without regard to XCDs finish 1-6 us later.)
+// Placement is a speed matter only.
+__host__ __device__ inline bool split_exact_grid(int total, int parts) { return total < 8 && parts == 8; }
+__device__ __forceinline__ void split_unit(int u, int total, int parts, int pix_parts, int &cand, int &part, int &pix_part)
 {
-    const int x = u & 7, t = u >> 3;
-    sub = t % kp;
-    cand = (t / kp) * 8 + x;
+    if (split_exact_grid(total, parts)) {
+        part = u & 7;
+        const int t = u >> 3;
+        cand = t % total;
+        pix_part = t / total;
+    } else {
+        const int x = u & 7, t = u >> 3, sub = t % (parts * pix_parts);
+        cand = (t / (parts * pix_parts)) * 8 + x;
+        part = sub % parts;
+        pix_part = sub / parts;
+    }
 }
 
 // Merge of the pixel parts of one row part (P > 1).  Pixel ranges 1..P-1 send their counters to range 0 as granules of
@@ -517,12 +530,11 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_split_kernel(GridArgs a
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds.joint != 0u) __builtin_trap();
     __syncthreads();
 
-    const int units = split_workgroups(total, K * P);
+    const int units = split_workgroups(total, K, P);
     unsigned long long prev_key = 0;
     for (int u = blockIdx.x; u < units; u += gridDim.x) {
-        int p, sub;
-        split_unit(u, K * P, p, sub);
-        const int part = sub % K, pix_part = sub / K;
+        int p, part, pix_part;
+        split_unit(u, total, K, P, p, part, pix_part);
         if (p >= total) continue;  // workgroup-uniform
         const int w = p / a.S_local, s = p - w * a.S_local;
         SplitSlab *slab = a.slabs + p;
@@ -555,7 +567,10 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_split_kernel(GridArgs a
     if (a.dbg_stamps && tid == 0) a.dbg_stamps[blockIdx.x * 8 + 7] = (unsigned long long)(clock64() - clk0);
 }
 
-__host__ __device__ int split_workgroups(int candidates, int parts_times_pix_parts) { return ((candidates + 7) / 8) * 8 * parts_times_pix_parts; }
+__host__ __device__ int split_workgroups(int candidates, int parts, int pix_parts)
+{
+    return (split_exact_grid(candidates, parts) ? candidates : ((candidates + 7) / 8) * 8) * parts * pix_parts;
+}
 
 template <int K, int P>
 static void launch_split_k(const GridArgs &a, dim3 grid, dim3 block, bool use_bg, hipStream_t stream)

@@ -22,7 +22,7 @@ with nmi.NmiContext(w, h) as ctx:
     ctx.set_option(ctx.OPT_SPLIT, K)
     ctx.set_option(ctx.OPT_SPLIT_PIXELS, P)
     ctx.set_option(ctx.OPT_PHASE_MASK, MASK)
-    n_wg = ((S * Wn + 7) // 8) * 8 * K * P
+    n_wg = (S * Wn if (S * Wn < 8 and K == 8) else ((S * Wn + 7) // 8) * 8) * K * P
     st = torch.zeros((n_wg, 8), dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
     for rep in range(5):
