@@ -46,6 +46,37 @@ __global__ void k(uint32_t *out, long long *cyc, int iters, uint32_t seed)
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// the same loop on `blocks` workgroups of 1024 lanes at once: does the rate per SIMD hold when the whole chip is busy?
+template <int KIND>
+static void run_chip(const char *name, int n_per_iter)
+{
+    uint32_t *out;
+    long long *cyc;
+    hipMalloc(&out, 4);
+    hipMalloc(&cyc, 8 * 4096);
+    const int iters = 2000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int blocks : {1, 8, 64, 256, 512}) {
+        hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(1024), 0, 0, out, cyc, iters, 1u);
+        hipDeviceSynchronize();
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(1024), 0, 0, out, cyc, iters, 2u);
+        hipEventRecord(e1, 0);
+        hipDeviceSynchronize();
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        long long c = 0;
+        hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+        const double instr_per_wave = (double)iters * 16 * n_per_iter;
+        printf("%-28s %4d workgroups x 16 waves: %6.2f ticks per instr per wave, wall %8.1f us -> %6.2f ns per instr per wave, %7.1f G wave-instr/s chip\n",
+               name, blocks, (double)c / instr_per_wave, ms * 1e3, ms * 1e6 / instr_per_wave, blocks * 16 * instr_per_wave / (ms * 1e-3) / 1e9);
+    }
+    hipFree(out);
+    hipFree(cyc);
+}
+
 template <int KIND>
 static void run(const char *name, int n_per_iter)
 {
@@ -78,5 +109,7 @@ int main()
     run<5>("and_or / mad_u24 / bfe / lshr", 4);
     run<4>("cmp+saveexec+add+s_or (VALU only counted: 4)", 4);
     run<6>("split dword: xor 2perm 4sdwa 4cmp", 11);
+    run_chip<0>("v_xor_b32 x4 independent", 4);
+    run_chip<5>("and_or/mad_u24/bfe/lshr", 4);
     return 0;
 }
