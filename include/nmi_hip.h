@@ -192,7 +192,8 @@ int nmi_render_points(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int6
  *   nmi_render_mesh     d_xyz float [3*T][3] and d_uv float [3*T][2]: the expanded per-corner arrays loadOBJ produces
  *                       (objloader.cpp:140-224); h_mvps as for nmi_render_points; output uint8 [S][H][W], bottom-up rows,
  *                       background 255.  Back faces culled (counter-clockwise front), depth test LESS, GL_REPEAT,
- *                       GL_LINEAR / GL_LINEAR_MIPMAP_LINEAR.  Triangles reaching behind the eye plane are dropped, not clipped.
+ *                       GL_LINEAR / GL_LINEAR_MIPMAP_LINEAR.  Triangles are clipped against the near plane in clip space
+ *                       (a ground plane passing under the camera keeps its visible part).
  * Enqueued on the context's stream.  Parity with an OpenGL driver is unpinned (kernel comment).
  */
 typedef struct nmi_texture nmi_texture;
@@ -295,6 +296,9 @@ int nmi_last_kernel_ms(nmi_ctx *ctx, float *h_ms);
 #define NMI_OPT_TILE_QUEUE 6   /* mesh renderer: capacity (work items) of the queue that hands large triangles to the
                                   tile pass, at most 4194304 (default); 0 = every triangle is shaded by its own lane.
                                   Same image for every value (small values exercise the overflow path in tests). */
+#define NMI_OPT_CLIP_QUEUE 11  /* mesh renderer: capacity of the queue that hands (triangle, view) pairs crossing the near plane to
+                                  the clipping pass, at most 262144 (default).  With more such pairs than that the clipping
+                                  pass finds them again itself; same image for every value (0 exercises that path in tests). */
 #define NMI_OPT_SPLIT 7        /* small grids (nmi_eval_pair, collapsed search levels): K workgroups per candidate, each owning
                                   256 / K rows of the joint histogram (no merge; bit-identical results).  -1 (default): K = 8
                                   up to 32 candidates, 4 up to 64 (on 256 compute units), none for larger grids; 0: never;

@@ -4,7 +4,10 @@ Restates Rendering<1>::renderToTextureOnGPU (Thirdparty/Localization/rendering.h
 ShadingWithTexture.* (luma 0.299/0.587/0.114 of the texture sample) and the texture state of loadBMP_custom
 (texture.cpp:31-96: GL_REPEAT, GL_LINEAR, GL_LINEAR_MIPMAP_LINEAR, glGenerateMipmap) with the OpenGL 3.3 specification's
 rules in fp32: pixel centres at +0.5, top-left fill rule, back-face culling (front = counter-clockwise), perspective-
-correct attributes, isotropic LOD from per-pixel uv differences, 2x2-box mip levels rounded to RGB8.
+correct attributes, isotropic LOD from per-pixel uv differences, 2x2-box mip levels rounded to RGB8, and clipping of
+triangles against the near plane in clip space (GL clips primitives to the view volume before the perspective divide:
+implied by glEnable(GL_DEPTH_TEST) / glDrawArrays(GL_TRIANGLES), rendering.hpp:294-300,619): Sutherland-Hodgman on
+z_clip >= -w_clip, new corners interpolated from the inside corner towards the outside one.
 "PARITY UNPINNED": an OpenGL driver rasterises in fixed point and may approximate the LOD; nothing to compare against.
 Slow (python loop over triangles): small test meshes only.
 """
@@ -55,31 +58,65 @@ def render_mesh(xyz, uv, levels, mvp_colmajor, width, height):
     P = np.asarray(xyz, f32).reshape(-1, 3, 3)
     T = np.asarray(uv, f32).reshape(-1, 3, 2)
     zbuf = np.full((height, width), 0xFFFFFFFF, np.uint32)
-    tw, th = f32(levels[0].shape[1]), f32(levels[0].shape[0])
-    nlev = len(levels)
     for tri in range(P.shape[0]):
         x, y, z = P[tri, :, 0], P[tri, :, 1], P[tri, :, 2]
         cx = (m[0] * x + m[4] * y) + (m[8] * z + m[12])
         cy = (m[1] * x + m[5] * y) + (m[9] * z + m[13])
         cz = (m[2] * x + m[6] * y) + (m[10] * z + m[14])
         cw = (m[3] * x + m[7] * y) + (m[11] * z + m[15])
+        tu, tv = T[tri, :, 0], T[tri, :, 1]
+        for sub in _clip_near(cx, cy, cz, cw, tu, tv):
+            _raster(zbuf, levels, width, height, *sub)
+    return (zbuf & np.uint32(0xFF)).astype(np.uint8)
+
+
+def _clip_near(cx, cy, cz, cw, tu, tv):
+    """Near-plane clipping of one triangle in clip space -> list of 0, 1 or 2 triangles, each (cx, cy, cz, cw, tu, tv) of 3."""
+    d = cz + cw
+    inside = d >= 0
+    n_in = int(inside.sum())
+    if n_in == 0:
+        return []
+    if n_in == 3:
+        return [(cx, cy, cz, cw, tu, tv)]
+    poly = []
+    for k in range(3):
+        b = (k + 1) % 3
+        if inside[k]:
+            poly.append((cx[k], cy[k], cz[k], cw[k], tu[k], tv[k]))
+        if inside[k] != inside[b]:
+            i, o = (k, b) if inside[k] else (b, k)   # from the inside corner towards the outside one
+            t = d[i] / (d[i] - d[o])
+            w = cw[i] + (cw[o] - cw[i]) * t
+            poly.append((cx[i] + (cx[o] - cx[i]) * t, cy[i] + (cy[o] - cy[i]) * t, -w, w, tu[i] + (tu[o] - tu[i]) * t,
+                         tv[i] + (tv[o] - tv[i]) * t))
+    out = []
+    for a_, b_, c_ in ((0, 1, 2), (0, 2, 3))[:len(poly) - 2]:
+        out.append(tuple(np.array([poly[a_][j], poly[b_][j], poly[c_][j]], f32) for j in range(6)))
+    return out
+
+
+def _raster(zbuf, levels, width, height, cx, cy, cz, cw, tu, tv):
+    tw, th = f32(levels[0].shape[1]), f32(levels[0].shape[0])
+    nlev = len(levels)
+    if True:
         if not (cw > 0).all():
-            continue
+            return
         if ((cx < -cw).all() or (cx > cw).all() or (cy < -cw).all() or (cy > cw).all() or (cz < -cw).all() or (cz > cw).all()):
-            continue
+            return
         xw = (cx / cw * f32(0.5) + f32(0.5)) * f32(width)
         yw = (cy / cw * f32(0.5) + f32(0.5)) * f32(height)
         zw = cz / cw * f32(0.5) + f32(0.5)
         iw = f32(1.0) / cw
         area = (xw[1] - xw[0]) * (yw[2] - yw[0]) - (xw[2] - xw[0]) * (yw[1] - yw[0])
         if not area > 0:
-            continue
+            return
         x_lo = max(0, int(np.ceil(xw.min() - f32(0.5))))
         x_hi = min(width - 1, int(np.floor(xw.max() - f32(0.5))))
         y_lo = max(0, int(np.ceil(yw.min() - f32(0.5))))
         y_hi = min(height - 1, int(np.floor(yw.max() - f32(0.5))))
         if x_lo > x_hi or y_lo > y_hi:
-            continue
+            return
         inv_area = f32(1.0) / area
         ex = np.array([xw[(k + 2) % 3] - xw[(k + 1) % 3] for k in range(3)], f32)
         ey = np.array([yw[(k + 2) % 3] - yw[(k + 1) % 3] for k in range(3)], f32)
@@ -87,7 +124,6 @@ def render_mesh(xyz, uv, levels, mvp_colmajor, width, height):
         yy, xx = np.mgrid[y_lo:y_hi + 1, x_lo:x_hi + 1]
         fxp = xx.astype(f32) + f32(0.5)
         fyp = yy.astype(f32) + f32(0.5)
-        tu, tv = T[tri, :, 0], T[tri, :, 1]
 
         def attrs(px, py):
             b = [(ex[k] * (py - yw[(k + 1) % 3]) - ey[k] * (px - xw[(k + 1) % 3])) * inv_area for k in range(3)]
@@ -104,7 +140,7 @@ def render_mesh(xyz, uv, levels, mvp_colmajor, width, height):
                 inside &= (b[k] > 0) | ((b[k] == 0) & own[k])
             inside &= (zz >= 0) & (zz <= 1)
             if not inside.any():
-                continue
+                return
             _, _, ux, vx = attrs(fxp + f32(1.0), fyp)
             _, _, uy, vy = attrs(fxp, fyp + f32(1.0))
             dudx, dvdx, dudy, dvdy = (ux - u) * tw, (vx - v) * th, (uy - u) * tw, (vy - v) * th
@@ -127,7 +163,6 @@ def render_mesh(xyz, uv, levels, mvp_colmajor, width, height):
         frag = (depth << np.uint32(8)) | colour
         sub = zbuf[y_lo:y_hi + 1, x_lo:x_hi + 1]
         sub[inside] = np.minimum(sub[inside], frag[inside])
-    return (zbuf & np.uint32(0xFF)).astype(np.uint8)
 
 
 def render_stack(xyz, uv, levels, mvps, width, height):

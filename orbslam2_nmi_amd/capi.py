@@ -241,7 +241,7 @@ class NmiContext:
             cur.synchronize()
 
     OPT_HIST_VARIANT, OPT_PHASE_MASK, OPT_WORKGROUPS, OPT_RESULT_PATH, OPT_XCD_TILING, OPT_TILE_QUEUE = 1, 2, 3, 4, 5, 6
-    OPT_SPLIT, OPT_WAIT_MODE, OPT_STAMPS, OPT_SPLIT_PIXELS = 7, 8, 9, 10
+    OPT_SPLIT, OPT_WAIT_MODE, OPT_STAMPS, OPT_SPLIT_PIXELS, OPT_CLIP_QUEUE = 7, 8, 9, 10, 11
 
     def set_option(self, option, value):
         self._check(self._lib.nmi_set_option(self._h, int(option), int(value)), "nmi_set_option")

@@ -503,6 +503,7 @@ int nmi_destroy(nmi_ctx *ctx)
     if (ctx->d_zbuf) (void)hipFree(ctx->d_zbuf);
     if (ctx->d_tile_queue) (void)hipFree(ctx->d_tile_queue);
     if (ctx->d_tile_state) (void)hipFree(ctx->d_tile_state);
+    if (ctx->d_clip_queue) (void)hipFree(ctx->d_clip_queue);
     for (int i = 0; i < StagingRing::kSlots; ++i) {
         if (ctx->mvp_ring.d[i]) (void)hipFree(ctx->mvp_ring.d[i]);
         if (ctx->mvp_ring.h[i]) (void)hipHostFree(ctx->mvp_ring.h[i]);
@@ -579,6 +580,10 @@ int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value)
     case NMI_OPT_TILE_QUEUE:
         if (value < 0 || value > (4ll << 20)) return NMI_ERR_INVALID_ARGUMENT;
         ctx->tile_queue_limit = (unsigned long long)value;
+        return NMI_OK;
+    case NMI_OPT_CLIP_QUEUE:
+        if (value < 0) return NMI_ERR_INVALID_ARGUMENT;
+        ctx->clip_queue_limit = (unsigned long long)value;
         return NMI_OK;
     case NMI_OPT_WORKGROUPS:
         if (value < 0 || value > (1 << 20)) return NMI_ERR_INVALID_ARGUMENT;

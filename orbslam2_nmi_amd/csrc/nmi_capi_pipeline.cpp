@@ -160,7 +160,7 @@ static int level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_attr, i
             ok(nmi::launch_render_mesh(d_xyz, d_attr, n_points, tex->d_luma, tex->levels, tex->w, tex->h, tex->off, lv->d_mvps, S, lv->d_zbuf,
                                        lv->d_renders, p.width, p.height, ctx->d_tile_queue,
                                        ctx->tile_queue_limit < ctx->tile_queue_cap ? ctx->tile_queue_limit : ctx->tile_queue_cap,
-                                       ctx->d_tile_state, st, /*clear_first=*/false));
+                                       ctx->d_tile_state, ctx->d_clip_queue, ctx->clip_queue_limit < ctx->clip_queue_cap ? ctx->clip_queue_limit : ctx->clip_queue_cap, st, /*clear_first=*/false));
         else
             ok(nmi::launch_render_points(d_xyz, d_red, n_points, lv->d_mvps, S, lv->d_zbuf, lv->d_renders, p.width, p.height, lv->size, st,
                                          /*clear_first=*/false));

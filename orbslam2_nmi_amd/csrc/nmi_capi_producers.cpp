@@ -15,7 +15,10 @@ int ensure_tile_queue(nmi_ctx *ctx)
     constexpr unsigned long long kItems = 4ull << 20;
     NMI_HIP_TRY(ctx, hipMalloc(&ctx->d_tile_queue, (size_t)kItems * nmi::mesh_tile_item_bytes()));
     ctx->tile_queue_cap = kItems;
-    NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tile_state, 2 * sizeof(unsigned long long)));
+    NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tile_state, 4 * sizeof(unsigned long long)));
+    constexpr unsigned long long kClipItems = 1ull << 18;  // (triangle, view) pairs crossing the near plane; beyond it: rescan
+    NMI_HIP_TRY(ctx, hipMalloc(&ctx->d_clip_queue, (size_t)kClipItems * nmi::mesh_clip_item_bytes()));
+    ctx->clip_queue_cap = kClipItems;
     return NMI_OK;
 }
 
@@ -259,7 +262,7 @@ int nmi_render_mesh(nmi_ctx *ctx, const float *d_xyz, const float *d_uv, int64_t
     NMI_HIP_TRY(ctx, nmi::launch_render_mesh(d_xyz, d_uv, n_triangles, tex->d_luma, tex->levels, tex->w, tex->h, tex->off, d_mvps, S,
                                              ctx->d_zbuf, d_render_stack, ctx->params.width, ctx->params.height, ctx->d_tile_queue,
                                              ctx->tile_queue_limit < ctx->tile_queue_cap ? ctx->tile_queue_limit : ctx->tile_queue_cap,
-                                             ctx->d_tile_state, ctx->stream));
+                                             ctx->d_tile_state, ctx->d_clip_queue, ctx->clip_queue_limit < ctx->clip_queue_cap ? ctx->clip_queue_limit : ctx->clip_queue_cap, ctx->stream));
     return NMI_OK;
 }
 

@@ -81,7 +81,10 @@ struct nmi_ctx {
     void *d_tile_queue = nullptr;          // mesh renderer: (triangle, view, tile) work items of large triangles
     unsigned long long tile_queue_cap = 0;      // allocated items
     unsigned long long tile_queue_limit = 4ull << 20;  // NMI_OPT_TILE_QUEUE
-    unsigned long long *d_tile_state = nullptr;  // [2] claimed / ~(first claim that did not fit)
+    unsigned long long *d_tile_state = nullptr;  // [4] tile items claimed / ~(first claim that did not fit) / clip items claimed / -
+    void *d_clip_queue = nullptr;          // mesh renderer: (triangle, view) pairs that cross the near plane
+    unsigned long long clip_queue_cap = 0;
+    unsigned long long clip_queue_limit = ~0ull;  // NMI_OPT_CLIP_QUEUE
     StagingRing mvp_ring;
     uint32_t *d_scratch = nullptr;        // drained-counter slabs of the pipelined kernel
     int scratch_workgroups = 0;

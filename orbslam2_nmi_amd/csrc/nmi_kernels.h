@@ -100,8 +100,10 @@ hipError_t launch_warp(const uint8_t *frame, const float *coeffs /*[Wn][9] inver
 hipError_t launch_render_mesh(const float *xyz, const float *uv, long long ntri, const float *luma, int levels, const int *lw,
                               const int *lh, const long long *loff, const float *mvps /*[S][16]*/, int S, uint32_t *zbuf /*[S][H][W]*/,
                               uint8_t *out, int width, int height, void *tile_queue, unsigned long long tile_queue_cap,
-                              unsigned long long *queue_state, hipStream_t stream, bool clear_first = true);
+                              unsigned long long *queue_state /*[4]*/, void *clip_queue, unsigned long long clip_queue_cap,
+                              hipStream_t stream, bool clear_first = true);
 size_t mesh_tile_item_bytes();
+size_t mesh_clip_item_bytes();  // items of the queue that hands triangles crossing the near plane to the clip kernel
 // Words between rows of the renderers' anchor / depth buffer: the padded width, rounded so that the resolve pass can
 // read 8 consecutive anchors of any output quad with two aligned 16-byte loads (point sizes > 1); width for size 1.
 inline int zbuf_stride(int width, int size) { return size > 1 ? ((width + size - 1 + 3) & ~3) + 4 : width; }

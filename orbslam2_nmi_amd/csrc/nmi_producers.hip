@@ -507,7 +507,13 @@ size_t render_zbuf_words(int S, int width, int height, int size) { return (size_
 // What follows is the OpenGL 3.3 pipeline in fp32 as the specification words it (pixel centres at +0.5, top-left
 // fill rule, perspective-correct interpolation, isotropic level of detail from the per-pixel uv derivatives); a real
 // driver rasterises in fixed point and is free in its LOD approximation, so parity with one is unpinned.
-// Simplification: a triangle with a vertex at w <= 0 (behind the eye plane) is dropped instead of clipped.
+// Clipping: triangles are clipped against the NEAR plane (z_clip >= -w_clip) in clip space, as the GL pipeline does before
+// the perspective divide (1 or 2 output triangles, clip coordinates and uv interpolated linearly along the cut edges,
+// always from the inside vertex towards the outside one so that two triangles sharing an edge cut it at the same
+// point).  A ground plane passing under the camera, a wall the camera stands next to -- the common case for a UAV over a
+// terrain mesh or a camera inside a city model -- therefore keeps its visible part.  The other five planes need no
+// geometric clipping: the pixel bounding box is clamped to the window and fragments beyond the far plane fail the
+// per-pixel depth-range test.
 // The texture arrives as per-level fp32 luma (host: nmi_texture_create), since every filter here is linear.
 struct MeshTexture {
     const float *luma;   // all levels, level l at luma + off[l], row-major, row 0 = v 0
@@ -549,20 +555,77 @@ struct TriView {
     int x_lo, x_hi, y_lo, y_hi;        // pixel bounding box, clamped to the window
 };
 
-__device__ __forceinline__ bool tri_setup(const float *__restrict__ m, const float (&px)[3], const float (&py)[3], const float (&pz)[3],
-                                          int width, int height, TriView &t)
+// A triangle in clip space after near-plane clipping: 3 or 4 corners in the original winding order with their uv.
+struct ClipPoly {
+    float cx[4], cy[4], cz[4], cw[4], u[4], v[4];
+    int n;  // 0 (nothing left), 3 or 4
+};
+
+// Clip coordinates of the three corners and their signed distances d = z + w to the near plane (inside iff >= 0).
+// Returns the number of corners inside.
+__device__ __forceinline__ int tri_clip_coords(const float *__restrict__ m, const float (&px)[3], const float (&py)[3], const float (&pz)[3],
+                                               float (&cx)[3], float (&cy)[3], float (&cz)[3], float (&cw)[3], float (&d)[3])
 {
-    float cx[3], cy[3], cz[3], cw[3];
-    bool behind = false;
+    int n_in = 0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         cx[k] = (m[0] * px[k] + m[4] * py[k]) + (m[8] * pz[k] + m[12]);
         cy[k] = (m[1] * px[k] + m[5] * py[k]) + (m[9] * pz[k] + m[13]);
         cz[k] = (m[2] * px[k] + m[6] * py[k]) + (m[10] * pz[k] + m[14]);
         cw[k] = (m[3] * px[k] + m[7] * py[k]) + (m[11] * pz[k] + m[15]);
-        behind = behind || !(cw[k] > 0.0f);
+        d[k] = cz[k] + cw[k];
+        n_in += d[k] >= 0.0f ? 1 : 0;
     }
-    if (behind) return false;
+    return n_in;
+}
+
+// The rare case (1 or 2 corners inside): Sutherland-Hodgman against the near plane; corners are appended in winding
+// order (3 or 4 of them).  Only the clip and tile kernels contain this code: nmi_mesh_kernel hands such triangles over.
+__device__ __forceinline__ void tri_clip_poly(const float (&cx)[3], const float (&cy)[3], const float (&cz)[3], const float (&cw)[3],
+                                           const float (&d)[3], const float (&tu)[3], const float (&tv)[3], ClipPoly &P)
+{
+    int n = 0;
+    auto push = [&](float x, float y, float z, float w, float uu, float vv) {
+        // n is 0..3 here; written as selects so that the arrays stay in registers
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j == n) P.cx[j] = x, P.cy[j] = y, P.cz[j] = z, P.cw[j] = w, P.u[j] = uu, P.v[j] = vv;
+        ++n;
+    };
+    P.cx[3] = P.cy[3] = P.cz[3] = P.cw[3] = P.u[3] = P.v[3] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int b = (k + 1) % 3;
+        const bool in_a = d[k] >= 0.0f, in_b = d[b] >= 0.0f;
+        if (in_a) push(cx[k], cy[k], cz[k], cw[k], tu[k], tv[k]);
+        if (in_a != in_b) {
+            const int i = in_a ? k : b, o = in_a ? b : k;  // from the inside corner towards the outside one
+            const float t = d[i] / (d[i] - d[o]);
+            const float w = cw[i] + (cw[o] - cw[i]) * t;
+            push(cx[i] + (cx[o] - cx[i]) * t, cy[i] + (cy[o] - cy[i]) * t, -w /* on the near plane */, w, tu[i] + (tu[o] - tu[i]) * t,
+                 tv[i] + (tv[o] - tv[i]) * t);
+        }
+    }
+    P.n = n;
+}
+
+// Corners (0, sub + 1, sub + 2) of a clipped polygon.
+__device__ __forceinline__ void poly_corners(const ClipPoly &P, int sub, float (&cx)[3], float (&cy)[3], float (&cz)[3], float (&cw)[3],
+                                             float (&su)[3], float (&sv)[3])
+{
+    cx[0] = P.cx[0], cy[0] = P.cy[0], cz[0] = P.cz[0], cw[0] = P.cw[0], su[0] = P.u[0], sv[0] = P.v[0];
+    cx[1] = sub ? P.cx[2] : P.cx[1], cy[1] = sub ? P.cy[2] : P.cy[1], cz[1] = sub ? P.cz[2] : P.cz[1], cw[1] = sub ? P.cw[2] : P.cw[1];
+    su[1] = sub ? P.u[2] : P.u[1], sv[1] = sub ? P.v[2] : P.v[1];
+    cx[2] = sub ? P.cx[3] : P.cx[2], cy[2] = sub ? P.cy[3] : P.cy[2], cz[2] = sub ? P.cz[3] : P.cz[2], cw[2] = sub ? P.cw[3] : P.cw[2];
+    su[2] = sub ? P.u[3] : P.u[2], sv[2] = sub ? P.v[3] : P.v[2];
+}
+
+// One triangle given by the clip coordinates of its corners, seen through the window transform.  Returns false if it
+// cannot produce a fragment.
+__device__ __forceinline__ bool tri_setup(const float (&cx)[3], const float (&cy)[3], const float (&cz)[3], const float (&cw)[3], int width,
+                                          int height, TriView &t)
+{
+    if (!(cw[0] > 0.0f) || !(cw[1] > 0.0f) || !(cw[2] > 0.0f)) return false;  // (a corner on or behind the eye plane survives near clipping only with a degenerate matrix)
     if ((cx[0] < -cw[0] && cx[1] < -cw[1] && cx[2] < -cw[2]) || (cx[0] > cw[0] && cx[1] > cw[1] && cx[2] > cw[2]) ||
         (cy[0] < -cw[0] && cy[1] < -cw[1] && cy[2] < -cw[2]) || (cy[0] > cw[0] && cy[1] > cw[1] && cy[2] > cw[2]) ||
         (cz[0] < -cw[0] && cz[1] < -cw[1] && cz[2] < -cw[2]) || (cz[0] > cw[0] && cz[1] > cw[1] && cz[2] > cw[2]))
@@ -640,10 +703,15 @@ __device__ __forceinline__ void tri_shade(const TriView &t, const float (&tu)[3]
     atomicMin(&img[(size_t)yy * width + xx], (depth << 8) | colour);
 }
 
-// Rasterisation in two kernels.
+// Rasterisation in three kernels (the middle one only has work when triangles cross the near plane).
 //  nmi_mesh_kernel       one lane per triangle, looping over the views (the mesh is read once).  A triangle whose pixel
 //                        bounding box in a view is at most kSmallBox pixels is shaded right there by its lane; a larger one
 //                        is cut into 64 x 64 pixel screen tiles and each (triangle, view, tile) goes into a work queue.
+//  nmi_mesh_clip_kernel  one lane per (triangle, view) that crosses the near plane -- handed over by nmi_mesh_kernel through a
+//                        second, small queue so that the clipping code (a 4-corner polygon in registers) stays out of the
+//                        kernel every triangle goes through: it clips, then shades small pieces itself and queues the
+//                        tiles of large ones (a ground plane under the camera is two huge triangles).  If that queue
+//                        overflows, this kernel finds the crossing triangles again by itself (a second pass over the mesh).
 //  nmi_mesh_tile_kernel  one wavefront per queue entry: it rebuilds the TriView (the same arithmetic) and sweeps the
 //                        tile's part of the bounding box, 64 pixels of a row at a time.
 // A lane walking a 2,000-pixel triangle alone (facades, floors: the meshes this renderer is for) kept its wavefront busy
@@ -652,15 +720,22 @@ __device__ __forceinline__ void tri_shade(const TriView &t, const float (&tu)[3]
 constexpr int kSmallBox = 16;
 constexpr int kTile = 64;
 
+struct ClipItem {
+    unsigned long long tri;
+    uint32_t view, pad;
+};
+
 struct TileItem {
     uint32_t tri;
-    uint32_t where;  // view | tile x << 8 | tile y << 20
+    uint32_t where;  // view (7 bits; at most 64 per launch) | sub-triangle << 7 | tile x << 8 | tile y << 20
 };
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void nmi_mesh_kernel(const float *__restrict__ xyz, const float *__restrict__ uv, long long ntri,
                                                        const float *__restrict__ mvps, int views, uint32_t *__restrict__ zbuf,
                                                        int width, int height, MeshTexture tex, TileItem *__restrict__ queue,
-                                                       unsigned long long *__restrict__ queue_state, unsigned long long queue_cap)
+                                                       unsigned long long *__restrict__ queue_state, unsigned long long queue_cap,
+                                                       ClipItem *__restrict__ clipq, unsigned long long *__restrict__ clip_state,
+                                                       unsigned long long clip_cap)
 {
     // queue_state[0]: entries claimed so far.  Claims are contiguous, so at most one claim straddles the capacity and
     // every later one lies beyond it: the entries actually written are [0, start of the first claim that did not fit),
@@ -693,8 +768,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (!valid) return;
     for (int s = 0; s < views; ++s) {
         if (beyond[s]) continue;  // block-uniform
+        float cx[3], cy[3], cz[3], cw[3], d[3];
+        const int n_in = tri_clip_coords(m_all + s * 16, px, py, pz, cx, cy, cz, cw, d);
+        if (n_in < 3) {
+            if (n_in > 0) {  // crosses the near plane: nmi_mesh_clip_kernel's business
+                const unsigned long long at = atomicAdd(&clip_state[0], 1ull);
+                if (at < clip_cap) clipq[at] = ClipItem{(unsigned long long)tri, (uint32_t)s, 0u};
+            }
+            continue;  // (n_in == 0: wholly in front of the near plane)
+        }
         TriView t;
-        if (!tri_setup(m_all + s * 16, px, py, pz, width, height, t)) continue;
+        if (!tri_setup(cx, cy, cz, cw, width, height, t)) continue;
         const int bw = t.x_hi - t.x_lo + 1, bh = t.y_hi - t.y_lo + 1;
         if (bw * bh > kSmallBox && queue != nullptr && tri <= 0xFFFFFFFFll) {
             const int tx0 = t.x_lo / kTile, tx1 = t.x_hi / kTile, ty0 = t.y_lo / kTile, ty1 = t.y_hi / kTile;
@@ -714,6 +798,72 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// One (triangle, view) that crosses the near plane: clip, then each of the 1 or 2 pieces goes the way of any triangle.
+__device__ __forceinline__ void clip_and_raster(const float *__restrict__ xyz, const float *__restrict__ uv, long long tri, int s,
+                                                const float *__restrict__ m, uint32_t *__restrict__ zbuf, int width, int height,
+                                                const MeshTexture &tex, TileItem *__restrict__ queue, unsigned long long *__restrict__ queue_state,
+                                                unsigned long long queue_cap)
+{
+    float px[3], py[3], pz[3], tu[3], tv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        px[k] = xyz[(tri * 3 + k) * 3], py[k] = xyz[(tri * 3 + k) * 3 + 1], pz[k] = xyz[(tri * 3 + k) * 3 + 2];
+        tu[k] = uv[(tri * 3 + k) * 2], tv[k] = uv[(tri * 3 + k) * 2 + 1];
+    }
+    float cx[3], cy[3], cz[3], cw[3], d[3];
+    const int n_in = tri_clip_coords(m, px, py, pz, cx, cy, cz, cw, d);
+    if (n_in == 0 || n_in == 3) return;  // not this kernel's (the rescan visits every triangle)
+    ClipPoly P;
+    tri_clip_poly(cx, cy, cz, cw, d, tu, tv, P);
+    for (int sub = 0; sub + 3 <= P.n; ++sub) {
+        TriView t;
+        float su[3], sv[3];
+        poly_corners(P, sub, cx, cy, cz, cw, su, sv);
+        if (!tri_setup(cx, cy, cz, cw, width, height, t)) continue;
+        const int bw = t.x_hi - t.x_lo + 1, bh = t.y_hi - t.y_lo + 1;
+        if (bw * bh > kSmallBox && queue != nullptr && tri <= 0xFFFFFFFFll) {
+            const int tx0 = t.x_lo / kTile, tx1 = t.x_hi / kTile, ty0 = t.y_lo / kTile, ty1 = t.y_hi / kTile;
+            const unsigned long long n = (unsigned long long)((tx1 - tx0 + 1) * (ty1 - ty0 + 1));
+            const unsigned long long at = atomicAdd(&queue_state[0], n);
+            if (at + n <= queue_cap) {
+                unsigned long long k = at;
+                for (int ty = ty0; ty <= ty1; ++ty)
+                    for (int tx = tx0; tx <= tx1; ++tx)
+                        queue[k++] = TileItem{(uint32_t)tri, (uint32_t)s | ((uint32_t)sub << 7) | ((uint32_t)tx << 8) | ((uint32_t)ty << 20)};
+                continue;
+            }
+            atomicMax(&queue_state[1], ~at);
+        }
+        uint32_t *img = zbuf + (size_t)s * width * height;
+        for (int yy = t.y_lo; yy <= t.y_hi; ++yy)
+            for (int xx = t.x_lo; xx <= t.x_hi; ++xx) tri_shade(t, su, sv, tex, xx, yy, img, width);
+    }
+}
+
+__global__ __launch_bounds__(256) void nmi_mesh_clip_kernel(const float *__restrict__ xyz, const float *__restrict__ uv, long long ntri,
+                                                            const float *__restrict__ mvps, int views, uint32_t *__restrict__ zbuf, int width,
+                                                            int height, MeshTexture tex, TileItem *__restrict__ queue,
+                                                            unsigned long long *__restrict__ queue_state, unsigned long long queue_cap,
+                                                            const ClipItem *__restrict__ clipq, const unsigned long long *__restrict__ clip_state,
+                                                            unsigned long long clip_cap)
+{
+    const unsigned long long claimed = clip_state[0];
+    const unsigned long long gid = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x, stride = (unsigned long long)gridDim.x * blockDim.x;
+    if (claimed <= clip_cap) {
+        for (unsigned long long i = gid; i < claimed; i += stride)
+            clip_and_raster(xyz, uv, (long long)clipq[i].tri, (int)clipq[i].view, mvps + clipq[i].view * 16, zbuf, width, height, tex, queue,
+                            queue_state, queue_cap);
+    } else {
+        // more crossing triangles than the queue holds: look at every (triangle, view) again
+        const unsigned long long all = (unsigned long long)ntri * (unsigned long long)views;
+        for (unsigned long long i = gid; i < all; i += stride) {
+            const long long tri = (long long)(i / (unsigned long long)views);
+            const int s = (int)(i % (unsigned long long)views);
+            clip_and_raster(xyz, uv, tri, s, mvps + s * 16, zbuf, width, height, tex, queue, queue_state, queue_cap);
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void nmi_mesh_tile_kernel(const float *__restrict__ xyz, const float *__restrict__ uv,
                                                            const float *__restrict__ mvps, uint32_t *__restrict__ zbuf, int width, int height,
                                                            MeshTexture tex, const TileItem *__restrict__ queue,
@@ -725,7 +875,7 @@ __global__ __launch_bounds__(64) void nmi_mesh_tile_kernel(const float *__restri
     for (unsigned long long i = blockIdx.x; i < count; i += gridDim.x) {
         const TileItem it = queue[i];
         const long long tri = it.tri;
-        const int s = (int)(it.where & 0xFFu), tx = (int)((it.where >> 8) & 0xFFFu), ty = (int)(it.where >> 20);
+        const int s = (int)(it.where & 0x7Fu), sub = (int)((it.where >> 7) & 1u), tx = (int)((it.where >> 8) & 0xFFFu), ty = (int)(it.where >> 20);
         float px[3], py[3], pz[3], tu[3], tv[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -733,7 +883,16 @@ __global__ __launch_bounds__(64) void nmi_mesh_tile_kernel(const float *__restri
             tu[k] = uv[(tri * 3 + k) * 2], tv[k] = uv[(tri * 3 + k) * 2 + 1];
         }
         TriView t;
-        if (!tri_setup(mvps + s * 16, px, py, pz, width, height, t)) continue;  // cannot happen: the same test passed before
+        float cx[3], cy[3], cz[3], cw[3], d[3];
+        float su[3] = {tu[0], tu[1], tu[2]}, sv[3] = {tv[0], tv[1], tv[2]};
+        const int n_in = tri_clip_coords(mvps + s * 16, px, py, pz, cx, cy, cz, cw, d);
+        if (n_in < 3) {
+            ClipPoly P;
+            tri_clip_poly(cx, cy, cz, cw, d, tu, tv, P);
+            if (n_in == 0 || sub + 3 > P.n) continue;
+            poly_corners(P, sub, cx, cy, cz, cw, su, sv);
+        }
+        if (!tri_setup(cx, cy, cz, cw, width, height, t)) continue;  // cannot happen: the same test passed before
         const int x0 = max(t.x_lo, tx * kTile), x1 = min(t.x_hi, tx * kTile + kTile - 1);
         const int y0 = max(t.y_lo, ty * kTile), y1 = min(t.y_hi, ty * kTile + kTile - 1);
         uint32_t *img = zbuf + (size_t)s * width * height;
@@ -742,7 +901,7 @@ __global__ __launch_bounds__(64) void nmi_mesh_tile_kernel(const float *__restri
         for (int by = y0; by <= y1; by += 8)
             for (int bx = x0; bx <= x1; bx += 8) {
                 const int xx = bx + lx, yy = by + ly;
-                if (xx <= x1 && yy <= y1) tri_shade(t, tu, tv, tex, xx, yy, img, width);
+                if (xx <= x1 && yy <= y1) tri_shade(t, su, sv, tex, xx, yy, img, width);
             }
     }
 }
@@ -750,7 +909,7 @@ __global__ __launch_bounds__(64) void nmi_mesh_tile_kernel(const float *__restri
 hipError_t launch_render_mesh(const float *xyz, const float *uv, long long ntri, const float *luma, int levels, const int *lw,
                               const int *lh, const long long *loff, const float *mvps, int S, uint32_t *zbuf, uint8_t *out,
                               int width, int height, void *tile_queue, unsigned long long tile_queue_cap, unsigned long long *queue_state,
-                              hipStream_t stream, bool clear_first)
+                              void *clip_queue, unsigned long long clip_queue_cap, hipStream_t stream, bool clear_first)
 {
     MeshTexture tex{};
     tex.luma = luma;
@@ -760,16 +919,20 @@ hipError_t launch_render_mesh(const float *xyz, const float *uv, long long ntri,
     if (clear_first)
         hipLaunchKernelGGL(nmi_zbuf_clear_kernel, dim3((unsigned)((nz + 255) / 256 < 4096 ? (nz + 255) / 256 : 4096)), dim3(256), 0, stream, zbuf, nz);
     if (ntri > 0) {
-        TileItem *queue = tile_queue_cap > 0 && queue_state ? static_cast<TileItem *>(tile_queue) : nullptr;
+        if (!queue_state || !clip_queue) return hipErrorInvalidValue;
+        TileItem *queue = tile_queue_cap > 0 ? static_cast<TileItem *>(tile_queue) : nullptr;
         for (int s0 = 0; s0 < S; s0 += kMaxViewsPerLaunch) {
             const int views = S - s0 < kMaxViewsPerLaunch ? S - s0 : kMaxViewsPerLaunch;
-            if (queue) {
-                const hipError_t e = hipMemsetAsync(queue_state, 0, 2 * sizeof(unsigned long long), stream);
-                if (e != hipSuccess) return e;
-            }
+            // queue_state: [0] tile items claimed, [1] ~(first claim that did not fit), [2] clip items claimed, [3] unused
+            const hipError_t e = hipMemsetAsync(queue_state, 0, 4 * sizeof(unsigned long long), stream);
+            if (e != hipSuccess) return e;
+            ClipItem *clipq = static_cast<ClipItem *>(clip_queue);
             hipLaunchKernelGGL(nmi_mesh_kernel, dim3((unsigned)((ntri + 255) / 256)), dim3(256), 0, stream, xyz, uv, ntri,
                                mvps + (size_t)s0 * 16, views, zbuf + (size_t)s0 * width * height, width, height, tex, queue, queue_state,
-                               tile_queue_cap);
+                               tile_queue_cap, clipq, queue_state + 2, clip_queue_cap);
+            hipLaunchKernelGGL(nmi_mesh_clip_kernel, dim3(512), dim3(256), 0, stream, xyz, uv, ntri, mvps + (size_t)s0 * 16, views,
+                               zbuf + (size_t)s0 * width * height, width, height, tex, queue, queue_state, tile_queue_cap, clipq,
+                               queue_state + 2, clip_queue_cap);
             if (queue)
                 hipLaunchKernelGGL(nmi_mesh_tile_kernel, dim3(16384), dim3(64), 0, stream, xyz, uv, mvps + (size_t)s0 * 16,
                                    zbuf + (size_t)s0 * width * height, width, height, tex, queue, queue_state);
@@ -780,6 +943,7 @@ hipError_t launch_render_mesh(const float *xyz, const float *uv, long long ntri,
 }
 
 size_t mesh_tile_item_bytes() { return sizeof(TileItem); }
+size_t mesh_clip_item_bytes() { return sizeof(ClipItem); }
 
 hipError_t launch_render_points(const float *xyz, const float *red, long long npoints, const float *mvps, int S, uint32_t *zbuf,
                                 uint8_t *out, int width, int height, int size, hipStream_t stream, bool clear_first)

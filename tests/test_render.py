@@ -239,6 +239,92 @@ def test_mesh_twin_sanity():
     assert 0 < (img2 != 255).mean() < 0.05
 
 
+def ground_mesh(w, h, y_ground=4.0, z_back=-30.0, z_front=80.0, half_width=60.0, strips=3):
+    """A ground plane BELOW the camera (camera at the origin looking along +z, up = -y, so larger y is lower) that starts far
+    behind the camera and runs past the far plane: `strips` x 2 large triangles, every one of them crossing the near plane
+    (and the eye plane w = 0).  Plus a wall next to the camera that also reaches behind it."""
+    rp = params(w, h)
+    xs = np.linspace(-half_width, half_width, strips + 1)
+    tris, uvs = [], []
+    for i in range(strips):
+        a, b = xs[i], xs[i + 1]
+        p00, p10, p01, p11 = (a, y_ground, z_back), (b, y_ground, z_back), (a, y_ground, z_front), (b, y_ground, z_front)
+        t00, t10, t01, t11 = (i / strips, 0.0), ((i + 1) / strips, 0.0), (i / strips, 4.0), ((i + 1) / strips, 4.0)
+        tris += [p00, p10, p11, p00, p11, p01]
+        uvs += [t00, t10, t11, t00, t11, t01]
+    wall = [(-3.0, -4.0, -10.0), (-3.0, y_ground, -10.0), (-3.0, y_ground, 40.0), (-3.0, -4.0, -10.0), (-3.0, y_ground, 40.0), (-3.0, -4.0, 40.0)]
+    tris += wall
+    uvs += [(0, 0), (0, 1), (3, 1), (0, 0), (3, 1), (3, 0)]
+    xyz = np.array(tris, np.float32)
+    uv = np.array(uvs, np.float32)
+    B = sy.scene(128, 128, 9)
+    rgb = np.stack([B, np.roll(B, 5, 0), np.roll(B, 9, 1)], -1).astype(np.uint8)
+    rgb = np.minimum(rgb, 250)  # keep the texture away from the background value
+    return xyz, uv, rgb, rp
+
+
+def _both_windings(xyz, uv):
+    """Every triangle twice, once per winding: whichever way the camera's handedness turns out, one copy faces it."""
+    x3, u3 = xyz.reshape(-1, 3, 3), uv.reshape(-1, 3, 2)
+    return np.concatenate([x3, x3[:, ::-1]]).reshape(-1, 3).copy(), np.concatenate([u3, u3[:, ::-1]]).reshape(-1, 2).copy()
+
+
+def test_mesh_twin_clips_triangles_at_the_near_plane():
+    """GL clips triangles against the view volume (rendering.hpp:294-300,619); a ground plane that passes under the camera
+    must cover the image below the horizon instead of vanishing because its corners lie behind the eye."""
+    w, h = 96, 72
+    xyz, uv, rgb, rp = ground_mesh(w, h)
+    xyz, uv = _both_windings(xyz, uv)
+    lv = mo.mip_luma(rgb)
+    m = capi.render_mvp(rp, (0, 0, 0), (0, 0, 1), (0, -1, 0), (0, 0, 0))
+    img = mo.render_mesh(xyz, uv, lv, m, w, h)
+    covered = img != 255
+    # The ground (4 m from the optical axis) is visible from the far plane (30 m: fy * 4 / 30 pixels off the horizon) to
+    # the near plane (5 m: beyond the image edge): one half of the image from a few rows off the horizon to its edge,
+    # whichever way this camera's up vector and row order turn it.
+    col = covered[:, w // 2]
+    off_far = int(np.ceil(rp.fy * 4.0 / rp.far_plane)) + 2
+    cy = int(round(rp.cy))
+    lower, upper = col[: cy - off_far], col[cy + off_far:]
+    assert lower.all() != upper.all() and (lower.all() or upper.all()), col.astype(int)
+    ground_rows = slice(0, cy - off_far) if lower.all() else slice(cy + off_far, h)
+    sky_rows = slice(cy + off_far, h) if lower.all() else slice(0, cy - off_far)
+    assert covered[ground_rows, 8: w - 8].mean() > 0.97       # ... across the width of the image
+    edge_row = 0 if lower.all() else h - 1
+    assert covered[edge_row].mean() > 0.9                       # including the row next to the near plane's cut
+    assert covered[sky_rows].mean() < 0.5                       # the other half: only the wall beside the camera
+    # every ground triangle has corners behind the eye: dropped instead of clipped, nothing at all would be drawn
+    assert covered.mean() > 0.4
+
+
+@pytest.mark.gpu
+def test_gpu_mesh_clipping_vs_twin():
+    """Triangles crossing the near plane / the eye plane: the HIP rasteriser (per-lane and tile-queue kernels) against the
+    numpy twin -- identical coverage and depth decisions, at most one grey level on a few pixels (LOD through log2f)."""
+    torch = pytest.importorskip("torch")
+    import orbslam2_nmi_amd as nmi
+    w, h = 320, 200
+    gx, gu, rgb, rp = ground_mesh(w, h)
+    gx, gu = _both_windings(gx, gu)
+    px, pu, _, _ = plane_mesh(w, h, depth=30.0, nx=6, ny=4)
+    xyz, uv = np.concatenate([gx, px]), np.concatenate([gu, pu])
+    mvps = np.stack([capi.render_mvp(rp, (0, 0, 0), (0, 0, 1), (0, -1, 0), t)
+                     for t in ((0, 0, 0), (0.4, -0.3, 1.0), (-0.8, 0.2, -3.0), (2.5, 0.5, 0), (0, -1.0, 2.0))])
+    exp = mo.render_stack(xyz, uv, mo.mip_luma(rgb), mvps, w, h)
+    assert ((exp != 255).mean(axis=(1, 2)) > 0.4).all()        # the ground is there in every view
+    outs = []
+    with nmi.NmiContext(w, h) as ctx, nmi.NmiTexture(ctx, rgb) as tex:
+        dx, du = torch.from_numpy(xyz).cuda(), torch.from_numpy(uv).cuda()
+        for cap, clip_cap in ((4 << 20, 1 << 18), (11, 1 << 18), (0, 1 << 18), (4 << 20, 3), (0, 0)):
+            ctx.set_option(ctx.OPT_TILE_QUEUE, cap)              # tile queue / overflowing tile queue / per-lane shading only
+            ctx.set_option(ctx.OPT_CLIP_QUEUE, clip_cap)         # clip queue / overflowing: the clip pass rescans the mesh
+            outs.append(ctx.render_mesh(dx, du, tex, mvps).cpu().numpy())
+    assert all((outs[0] == o).all() for o in outs[1:])
+    diff = np.abs(outs[0].astype(int) - exp.astype(int))
+    assert ((outs[0] == 255) == (exp == 255)).all()
+    assert diff.max() <= 1 and (diff != 0).mean() < 2e-3, (diff.max(), (diff != 0).mean())
+
+
 @pytest.mark.gpu
 def test_gpu_mesh_vs_twin():
     torch = pytest.importorskip("torch")
