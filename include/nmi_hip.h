@@ -300,16 +300,17 @@ int nmi_last_kernel_ms(nmi_ctx *ctx, float *h_ms);
                                   the clipping pass, at most 262144 (default).  With more such pairs than that the clipping
                                   pass finds them again itself; same image for every value (0 exercises that path in tests). */
 #define NMI_OPT_SPLIT 7        /* small grids (nmi_eval_pair, collapsed search levels): K workgroups per candidate, each owning
-                                  256 / K rows of the joint histogram (no merge; bit-identical results).  -1 (default): K = 8
-                                  up to 32 candidates, 4 up to 64 (on 256 compute units), none for larger grids; 0: never;
-                                  2 / 4 / 8: that K whenever the grid fits. */
+                                  256 / K rows of the joint histogram, optionally x P pixel ranges (NMI_OPT_SPLIT_PIXELS);
+                                  bit-identical results.  -1 (default, on 256 compute units): 8 x 4 up to 8 candidates, 8 x 2
+                                  up to 16, 4 x 2 up to 32, 4 x 1 up to 64, none for larger grids; 0: never; 2 / 4 / 8: that
+                                  K whenever the grid fits. */
 #define NMI_OPT_WAIT_MODE 8    /* how a blocking call waits for the posted result: 0 (default) spins on the pinned word
                                   (lowest latency, occupies the calling core for the search), 1 yields the core between
                                   polls (sched_yield; for hosts whose other threads need the core, e.g. ORB-SLAM2's
                                   LocalMapping / LoopClosing).  NMI_OPT_RESULT_PATH 0 sleeps in hipStreamSynchronize instead. */
-#define NMI_OPT_SPLIT_PIXELS 10 /* with 8 row parts, additionally cut the pixels of each pair into 2 or 4 ranges (one workgroup per
-                                  row part and range, merged per row part: nmi_eval_pair = 32 workgroups).  -1 (default): 4 / 2
-                                  when the launch then still fits the compute units; 1: never; 2 / 4: that many when it fits. */
+#define NMI_OPT_SPLIT_PIXELS 10 /* additionally cut the pixels of each pair into 2 or 4 ranges (one workgroup per row part and
+                                  range, merged per row part: nmi_eval_pair = 8 x 4 = 32 workgroups; 4 with 8 row parts only).
+                                  -1 (default): see NMI_OPT_SPLIT; 1: never; 2 / 4: that many when it exists and fits. */
 #define NMI_OPT_STAMPS 9       /* profiling tools only: value = device pointer to uint64 [workgroups][8]; workgroups of the
                                   split kernel store wall-clock stamps (100 MHz) at their phase boundaries there; 0 = off */
 int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value);

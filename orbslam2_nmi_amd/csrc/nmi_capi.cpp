@@ -74,28 +74,37 @@ int ensure_order(nmi_ctx *ctx, int S, int Wn, const int **d_order)
 }
 
 // How the split kernel should cut each candidate of a launch of `total` candidates on `cap` workgroups: *parts row
-// parts (8 / 4 / 2: the largest whose workgroups all run at once) and, for the smallest grids, *pix_parts pixel ranges
-// (4 / 2, only with 8 row parts).  *parts = 0: use the one-workgroup-per-candidate kernel.
+// parts and *pix_parts pixel ranges.  *parts = 0: use the one-workgroup-per-candidate kernel.  Automatic choice (256
+// CUs): up to 8 candidates 8 x 4, up to 16: 8 x 2, up to 32: 4 x 2, up to 64: 4 x 1 -- a part's time is its pixel stream
+// (>= 12 us for a whole 640x480 pair whatever the number of row parts), so pixel ranges come first and 2 row parts,
+// measured no faster than none, are available on request only.
 static void choose_split(const nmi_ctx *ctx, int64_t total, int cap, int *parts, int *pix_parts)
 {
     *parts = 0;
     *pix_parts = 1;
     if (ctx->hist_variant != 3 || ctx->split_mode == 0 || total <= 0 || total > cap) return;
     auto fits = [&](int k, int p) { return nmi::split_workgroups((int)total, k, p) <= cap; };
+    auto exists = [](int k, int p) { return p == 1 || (k == 8 && (p == 2 || p == 4)) || (k == 4 && p == 2); };
+    const int want_p = ctx->split_pixels;  // -1 automatic, 1 never, 2 / 4 that many when it fits
     if (ctx->split_mode > 0) {
-        if (!fits(ctx->split_mode, 1)) return;
-        *parts = ctx->split_mode;
-    } else {
-        for (int k = 8; k >= 4 && !*parts; k >>= 1)  // 2 row parts are available on request only: measured no faster than none
-            if (fits(k, 1)) *parts = k;
-        if (!*parts) return;
+        const int k = ctx->split_mode;
+        if (!fits(k, 1)) return;
+        *parts = k;
+        if (want_p == 1) return;
+        for (int p = 4; p >= 2; p >>= 1)
+            if ((want_p == -1 || want_p == p) && exists(k, p) && fits(k, p)) {
+                *pix_parts = p;
+                return;
+            }
+        return;
     }
-    if (*parts == 8 && ctx->split_pixels != 1) {
-        if (ctx->split_pixels > 1) {
-            if (fits(8, ctx->split_pixels)) *pix_parts = ctx->split_pixels;
-        } else {
-            for (int p = 4; p >= 2 && *pix_parts == 1; p >>= 1)
-                if (fits(8, p)) *pix_parts = p;
+    static const int order[][2] = {{8, 4}, {8, 2}, {4, 2}, {8, 1}, {4, 1}};
+    for (const auto &kp : order) {
+        if (kp[1] > 1 && want_p != -1 && want_p != kp[1]) continue;
+        if (fits(kp[0], kp[1])) {
+            *parts = kp[0];
+            *pix_parts = kp[1];
+            return;
         }
     }
 }

@@ -433,7 +433,7 @@ __device__ __forceinline__ void final_split(const SplitLds<K> &lds, const GridAr
 //     every XCD's L2 serves a share of the pixel stream.  (One pair: 32 workgroups instead of 256 dispatched, 1.2 us
 //     less per blocking call; the same 32 workgroups dealt without regard to XCDs finish 1-6 us later.)
 // Placement is a speed matter only.
-__host__ __device__ inline bool split_exact_grid(int total, int parts) { return total < 8 && parts == 8; }
+__host__ __device__ inline bool split_exact_grid(int total, int parts) { return total < 8 && parts == 8; }  // (row part j on XCD j needs 8 of them)
 __device__ __forceinline__ void split_unit(int u, int total, int parts, int pix_parts, int &cand, int &part, int &pix_part)
 {
     if (split_exact_grid(total, parts)) {
@@ -585,12 +585,14 @@ static void launch_split_k(const GridArgs &a, dim3 grid, dim3 block, bool use_bg
 hipError_t launch_split(const GridArgs &a, int parts, int pix_parts, int workgroups, bool use_bg, hipStream_t stream)
 {
     if (!a.slabs || workgroups <= 0 || (workgroups & 7)) return hipErrorInvalidValue;
-    if (pix_parts > 1 && (parts != 8 || !a.blocks)) return hipErrorInvalidValue;
+    if (pix_parts > 1 && !a.blocks) return hipErrorInvalidValue;
     dim3 grid(workgroups), block(kBlock);
-    if (pix_parts == 4)
+    if (pix_parts == 4 && parts == 8)
         launch_split_k<8, 4>(a, grid, block, use_bg, stream);
-    else if (pix_parts == 2)
+    else if (pix_parts == 2 && parts == 8)
         launch_split_k<8, 2>(a, grid, block, use_bg, stream);
+    else if (pix_parts == 2 && parts == 4)
+        launch_split_k<4, 2>(a, grid, block, use_bg, stream);
     else if (pix_parts != 1)
         return hipErrorInvalidValue;
     else
