@@ -287,7 +287,9 @@ int nmi_last_kernel_ms(nmi_ctx *ctx, float *h_ms);
                                   experiments 0 (per-pixel wrap test), 2 (unchecked) and 4 (histogram and decode overlapped by
                                   wavefront role; exact but slower) exist only in a library built with
                                   -DNMI_BUILD_ABLATIONS (NMI_ERR_UNSUPPORTED otherwise). */
-#define NMI_OPT_PHASE_MASK 2   /* bit 0 histogram phase, bit 1 decode + score, bit 2 disable the flat-chunk shortcut; default 3 */
+#define NMI_OPT_PHASE_MASK 2   /* bit 0 histogram phase, bit 1 decode + score, bit 2 disable the flat-chunk shortcut; default 3.
+                                  Bit 9 (tests): one part of the split kernel withholds its hand-off, so the bounded wait of
+                                  the scoring workgroup times out and the call is redone by the one-workgroup kernel. */
 #define NMI_OPT_WORKGROUPS 3   /* workgroups per launch; 0 = one per compute unit (default) */
 #define NMI_OPT_RESULT_PATH 4  /* how the 8-byte winner reaches the host: 1 the kernel posts it to pinned host memory
                                   and the call polls it (default), 0 hipMemcpyAsync + hipStreamSynchronize */

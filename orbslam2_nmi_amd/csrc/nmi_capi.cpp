@@ -280,9 +280,11 @@ bool split_timed_out(nmi_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     *ctx->h_split_error = 0;
     ctx->split_mode = 0;
-    ctx->detail = "split kernel hand-off timed out; split forms disabled for this context";
     return true;
 }
+
+// what nmi_last_error_detail says after a call that was redone because of such a timeout (the call itself succeeded)
+static const char *const kSplitTimeoutNote = "split kernel hand-off timed out; call redone without it, split forms disabled for this context";
 
 // Polls a pinned host word until (word & mask) == want; *out receives the word.  NMI_OPT_WAIT_MODE 0 spins (lowest
 // latency; occupies the calling core for the duration of the search), 1 yields the core between polls (the Tracking
@@ -575,7 +577,7 @@ int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value)
         ctx->wait_mode = (int)value;
         return NMI_OK;
     case NMI_OPT_PHASE_MASK:
-        if (value < 0 || value > 511) return NMI_ERR_INVALID_ARGUMENT;
+        if (value < 0 || value > 1023) return NMI_ERR_INVALID_ARGUMENT;
         ctx->phase_mask = (int)value;
         return NMI_OK;
     case NMI_OPT_XCD_TILING:
@@ -683,9 +685,12 @@ int nmi_search_grid_block(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S_l
         unsigned long long k = 0;
         rc = fetch_key(ctx, &k);
         if (rc != NMI_OK) return rc;
-        if (split_timed_out(ctx))
-            return nmi_search_grid_block(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn_local, w_offset, Wn_total,
-                                         d_ratings, d_key, h_key);
+        if (split_timed_out(ctx)) {
+            rc = nmi_search_grid_block(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn_local, w_offset, Wn_total, d_ratings,
+                                       d_key, h_key);
+            if (rc == NMI_OK) ctx->detail = kSplitTimeoutNote;
+            return rc;
+        }
         *h_key = k;
         // The winner is posted by the last workgroup before the kernel has retired: a caller that asked for the rating
         // table may read it right after this call, from any stream, so the table must be complete (and written back).
@@ -718,8 +723,11 @@ int nmi_eval_pair_debug(nmi_ctx *ctx, const uint8_t *render, const uint8_t *warp
         // (score bits | call number << 32) into pinned host memory and the call polls that word (~10 us less per call).
         unsigned long long word = 0;
         rc = wait_word(ctx, ctx->score_mailbox, 0xFFFFFFFF00000000ull, (unsigned long long)ctx->pair_seq << 32, &word);
-        if (rc == NMI_OK && split_timed_out(ctx))
-            return nmi_eval_pair_debug(ctx, render, warped, h_score, d_joint, d_hist_render, d_hist_warped, d_sums);
+        if (rc == NMI_OK && split_timed_out(ctx)) {
+            rc = nmi_eval_pair_debug(ctx, render, warped, h_score, d_joint, d_hist_render, d_hist_warped, d_sums);
+            if (rc == NMI_OK) ctx->detail = kSplitTimeoutNote;
+            return rc;
+        }
         if (rc == NMI_OK) {
             const uint32_t bits = (uint32_t)word;
             memcpy(h_score, &bits, sizeof bits);
@@ -730,7 +738,11 @@ int nmi_eval_pair_debug(nmi_ctx *ctx, const uint8_t *render, const uint8_t *warp
     }
     NMI_HIP_TRY(ctx, hipMemcpyAsync(h_score, ctx->d_pair_rating, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (split_timed_out(ctx)) return nmi_eval_pair_debug(ctx, render, warped, h_score, d_joint, d_hist_render, d_hist_warped, d_sums);
+    if (split_timed_out(ctx)) {
+        rc = nmi_eval_pair_debug(ctx, render, warped, h_score, d_joint, d_hist_render, d_hist_warped, d_sums);
+        if (rc == NMI_OK) ctx->detail = kSplitTimeoutNote;
+        return rc;
+    }
     return NMI_OK;
 }
 
@@ -787,7 +799,11 @@ int nmi_eval_pairs(nmi_ctx *ctx, const uint8_t *const *h_renders, const uint8_t 
     }
     NMI_HIP_TRY(ctx, hipMemcpyAsync(h_scores, ctx->d_pair_scores, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (split_timed_out(ctx)) return nmi_eval_pairs(ctx, h_renders, h_warps, n, h_scores);  // now one pair at a time
+    if (split_timed_out(ctx)) {  // now one pair at a time
+        const int rc = nmi_eval_pairs(ctx, h_renders, h_warps, n, h_scores);
+        if (rc == NMI_OK) ctx->detail = kSplitTimeoutNote;
+        return rc;
+    }
     return NMI_OK;
 }
 

@@ -550,7 +550,8 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_split_kernel(GridArgs a
         __syncthreads();
         stamp(3);
         if (tid < kBins) {
-            store_granule(&slab->hw_part[part][tid], granule32(lds.hist_warped[tid], a.epoch));
+            // (phase mask bit 9, tests only: part 1 keeps its column sums to itself, so the scorer's wait must time out)
+            if (!((a.phase_mask & 512) && part == 1)) store_granule(&slab->hw_part[part][tid], granule32(lds.hist_warped[tid], a.epoch));
             lds.hist_warped[tid] = 0;
         }
         if (part != 0) continue;  // workgroup-uniform: only part 0 scores the candidate

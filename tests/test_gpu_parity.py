@@ -585,6 +585,33 @@ def test_eval_pairs_equals_single_calls(nmi):
             assert [np.float32(x) for x in got] == [single[(r, (r * 5) % 12)] for r in range(12)], mode
 
 
+def test_split_hand_off_timeout_falls_back(nmi):
+    """The split kernel's scoring workgroup waits (bounded) for the other parts' granules.  If they never come -- here one
+    part is told to withhold them; in the field: fewer usable compute units than the device reports -- the kernel raises a
+    flag instead of hanging, and the host redoes the call with the one-workgroup-per-candidate kernel and keeps the split
+    forms off for that context.  Results stay the oracle's."""
+    from oracle import binding as oc
+    from orbslam2_nmi_amd import synthetic as sy
+    wl = sy.workload(160, 120, 3, 2, seed=6)
+    rs, ws = dev(wl["render_stack"]), dev(wl["warp_stack"])
+    with oc.rounded():
+        ro, io, bo = oc.search_grid(wl["render_stack"], wl["warp_stack"])
+    with nmi.NmiContext(160, 120) as ctx:
+        assert ctx.search_grid(rs, ws) == (io, bo)                      # split kernel (6 candidates -> 8 x 4 parts)
+        ctx.set_option(ctx.OPT_PHASE_MASK, 3 | 512)
+        t = torch.zeros(2, 3, device="cuda")
+        assert ctx.search_grid(rs, ws, t) == (io, bo)                   # times out (>= 30 ms), redone without the split
+        assert (t.cpu().numpy() == ro).all()
+        assert "timed out" in ctx._lib.nmi_last_error_detail(ctx._h).decode()
+        assert ctx.eval_pair(rs[1], ws[1]) == ro[1, 1]                  # the split forms are off now: no second timeout
+        ctx.set_option(ctx.OPT_PHASE_MASK, 3)
+        assert ctx.search_grid(rs, ws) == (io, bo)
+    with nmi.NmiContext(160, 120) as ctx:                                # the same for the per-candidate entry
+        ctx.set_option(ctx.OPT_PHASE_MASK, 3 | 512)
+        assert ctx.eval_pair(rs[2], ws[0]) == ro[0, 2]
+        assert ctx.eval_pairs([rs[0], rs[1]], [ws[1], ws[0]]).tolist() == [ro[1, 0], ro[0, 1]]
+
+
 def test_invalid_arguments_fail_loudly(nmi):
     with nmi.NmiContext(64, 48) as ctx:
         with pytest.raises(TypeError):
