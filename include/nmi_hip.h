@@ -73,7 +73,11 @@ int nmi_params_default(nmi_params *p, int32_t width, int32_t height);
  * (7 cudaMalloc kernel.cu:67-73, initHistogram256all NMI.cu:171-177, the frees at kernel.cu:103-109
  * and closeHistogram256all NMI.cu:180-185) and the file-static buffers NMI.cu:165-167.
  * One context = one stream; not thread-safe across threads (the reference is called from the
- * Tracking thread only, src/Tracking.cc:1886).
+ * Tracking thread only, src/Tracking.cc:1886).  Several contexts may search at the same time from several threads; if they
+ * score SMALL grids (up to 64 candidates) concurrently, give each a share of the device with NMI_OPT_WORKGROUPS
+ * (e.g. compute units / number of contexts): the split kernel used for small grids wants all workgroups of a launch
+ * resident at once, and two such launches that together exceed the device make each other wait until a 30 ms guard
+ * ends the wait and the calls are redone by the other kernel (correct results, one slow call, split forms off afterwards).
  */
 int nmi_create(const nmi_params *params, nmi_ctx **out_ctx);
 int nmi_destroy(nmi_ctx *ctx);

@@ -105,6 +105,17 @@ int nmi_search_grid_block_rccl(nmi_ctx *ctx, const uint8_t *render_stack, int32_
                                    nullptr, nullptr);
     if (rc != NMI_OK) return rc;
     DeviceGuard guard(ctx->device);
+    if (ctx->last_parts) {
+        // A small block went to the split kernel, whose hand-offs can time out (nmi_split_kernel.hip).  Every rank must
+        // issue exactly one collective with a valid key, so this rank settles its own search first: wait, and on a
+        // timeout redo it with the one-workgroup kernel (the split forms are then off for this context).
+        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (split_timed_out(ctx)) {
+            rc = nmi_search_grid_block(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn_local, w_offset, Wn_total, d_ratings,
+                                       nullptr, nullptr);
+            if (rc != NMI_OK) return rc;
+        }
+    }
     // The only exchange of the search: 8 bytes per rank, max over ranks.  Out of place: the send
     // buffer is this launch's key slot (zero for a rank whose block is empty), the receive buffer a word of its own, so
     // the global winner never lands in a ping-pong slot that a later launch expects to find zero.
@@ -113,8 +124,6 @@ int nmi_search_grid_block_rccl(nmi_ctx *ctx, const uint8_t *render_stack, int32_
     if (r != 0) return rccl_fail(ctx, r, "ncclAllReduce");
     NMI_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_key, ctx->d_reduced_key, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    // (a redo on this rank alone would issue a second collective; report it instead -- the split forms are now off)
-    if (split_timed_out(ctx)) return NMI_ERR_NOT_READY;
     return nmi_key_unpack(*ctx->h_key, h_best_index, h_best_score);
 }
 
