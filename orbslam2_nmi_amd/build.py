@@ -43,11 +43,17 @@ def is_stale():
     return any(os.path.getmtime(f) > t for f in sources() + headers() + [os.path.abspath(__file__)])
 
 
-def command():
+# The experiments of DESIGN.md section 4 (histogram variants 0 / 2 / 4) are not part of the shipped library; a second
+# library with them is built on request:  python -m orbslam2_nmi_amd.build --ablations  -> lib/libnmi_hip_ablate.so, which
+# tools/ablate.py loads through NMI_HIP_LIBRARY.
+ABLATE_LIB = os.path.join(LIB_DIR, "libnmi_hip_ablate.so")
+
+
+def command(ablations=False):
     return ["hipcc", "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared", "-ffp-contract=off",
-            "-Wall", "-Wno-unused-function",
+            "-Wall", "-Wno-unused-function", *(["-DNMI_BUILD_ABLATIONS"] if ablations else []),
             "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"), "-I" + os.path.join(PKG, "host"),
-            *sources(), "-o", LIB, "-ldl"]
+            *sources(), "-o", ABLATE_LIB if ablations else LIB, "-ldl"]
 
 
 def build(force=False, verbose=False):
@@ -62,4 +68,9 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--ablations" in sys.argv:
+        os.makedirs(LIB_DIR, exist_ok=True)
+        subprocess.check_call(command(ablations=True))
+        print(ABLATE_LIB)
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

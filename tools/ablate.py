@@ -5,6 +5,9 @@
 
 Prints median / min kernel time per (data, variant) for the config-2 grid (27 x 27 candidates at 640x480).
 Variants: histogram wrap handling (NMI_OPT_HIST_VARIANT) x phases executed (NMI_OPT_PHASE_MASK).
+Variants 0 / 2 / 4 exist only in the ablation build of the library:
+  python -m orbslam2_nmi_amd.build --ablations && NMI_HIP_LIBRARY=orbslam2_nmi_amd/lib/libnmi_hip_ablate.so python tools/ablate.py
+(with the shipped library they are skipped).
 """
 import argparse
 import json
@@ -50,6 +53,14 @@ def main():
                 ("decode-only", 3, 2), ("empty loop", 3, 0)]
     ctx = nmi.NmiContext(W, H)
     ctx.set_profiling(True)
+    usable = []
+    for v in variants:  # the shipped library has variants 1 and 3 only
+        try:
+            ctx.set_option(ctx.OPT_HIST_VARIANT, v[1])
+            usable.append(v)
+        except nmi.NmiError:
+            print(f"skipping '{v[0]}': variant {v[1]} is not in this build of the library (see the header of this file)")
+    variants = usable
     times = {(d, v[0]): [] for d in dev for v in variants}
     for rnd in range(args.rounds + 1):
         for d, (rs, ws) in dev.items():
