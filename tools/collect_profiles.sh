@@ -12,14 +12,14 @@ python3 bench.py --blocking --no-cpu-baseline > "$OUT/bench_blocking.json" 2>> "
 python3 bench.py --streams 2 --no-cpu-baseline > "$OUT/bench_2streams.json" 2>> "$OUT/bench.err" || exit 1
 python3 bench.py --config stream > "$OUT/bench_stream.json" 2>> "$OUT/bench.err" || exit 1
 python3 bench.py --config e2e > "$OUT/bench_e2e.json" 2>> "$OUT/bench.err" || exit 1
-python3 bench.py --config c3 --steps 50 --cpu-budget 6 > "$OUT/bench_c3.json" 2>> "$OUT/bench.err" || exit 1
-python3 bench.py --config c4 --steps 50 --cpu-budget 6 > "$OUT/bench_c4.json" 2>> "$OUT/bench.err" || exit 1
+python3 bench.py --config c3 --steps 300 --cpu-budget 6 > "$OUT/bench_c3.json" 2>> "$OUT/bench.err" || exit 1
+python3 bench.py --config c4 --steps 300 --cpu-budget 6 > "$OUT/bench_c4.json" 2>> "$OUT/bench.err" || exit 1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --steps 50 --warmup 5 --no-cpu-baseline > "$OUT/trace.log" 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --no-cpu-baseline > "$OUT/trace.log" 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" --steps 20 --warmup 2 --no-cpu-baseline > "$OUT/pmc_fetch.log" 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$ROOT/bench.py" --steps 20 --warmup 2 --no-cpu-baseline > "$OUT/pmc_write.log" 2>&1 || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c3" -- python3 "$ROOT/bench.py" --config c3 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/trace_c3.log" 2>&1 || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c4" -- python3 "$ROOT/bench.py" --config c4 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/trace_c4.log" 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c3" -- python3 "$ROOT/bench.py" --config c3 --steps 300 --no-cpu-baseline > "$OUT/trace_c3.log" 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c4" -- python3 "$ROOT/bench.py" --config c4 --steps 300 --no-cpu-baseline > "$OUT/trace_c4.log" 2>&1 || exit 1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU --output-format csv -d "$OUT/pmc_lds" -- python3 "$ROOT/bench.py" --steps 20 --warmup 2 --no-cpu-baseline > "$OUT/pmc_lds.log" 2>&1 || exit 1
 cd "$ROOT"
 python3 tools/summarize_profiles.py "$OUT"
