@@ -317,6 +317,13 @@ int nmi_last_kernel_ms(nmi_ctx *ctx, float *h_ms);
 #define NMI_OPT_SPLIT_PIXELS 10 /* additionally cut the pixels of each pair into 2 or 4 ranges (one workgroup per row part and
                                   range, merged per row part: nmi_eval_pair = 8 x 4 = 32 workgroups; 4 with 8 row parts only).
                                   -1 (default): see NMI_OPT_SPLIT; 1: never; 2 / 4: that many when it exists and fits. */
+#define NMI_OPT_CONTENT_PATH 12 /* frames with few distinct intensities (posterised, thresholded, quantised): -1 (default)
+                                  automatic -- every 32nd search is probed for the number of distinct intensities in its two
+                                  stacks (nr, nw), and while nr * nw <= NMI_OPT_FEWLEVELS_BINS searches go down the few-levels
+                                  path (rank images + 32-bit replicated counters; csrc/nmi_fewlevels_kernel.hip); 0: never;
+                                  1: always try it first.  Every few-levels search probes its own stacks and falls back to
+                                  the general kernel on the device when they do not qualify: results never depend on it. */
+#define NMI_OPT_FEWLEVELS_BINS 13 /* largest nr * nw sent down the few-levels path (1..4096, default 4096) */
 #define NMI_OPT_STAMPS 9       /* profiling tools only: value = device pointer to uint64 [workgroups][8]; workgroups of the
                                   split kernel store wall-clock stamps (100 MHz) at their phase boundaries there; 0 = off */
 int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value);
@@ -330,6 +337,10 @@ int nmi_abi_version(void);
 const char *nmi_error_string(int code);
 const char *nmi_last_error_detail(nmi_ctx *ctx); /* text of the last failing HIP/RCCL call, or "" */
 int nmi_get_info(nmi_ctx *ctx, int32_t *compute_units, int32_t *workgroups_per_launch, int32_t *lds_bytes);
+/* How the most recent search was scored (waits for it): *few_levels = 1 if it was sent down the few-levels path
+ * (NMI_OPT_CONTENT_PATH) AND stayed there, 0 if the general kernel scored it; *nr, *nw = distinct intensities the most
+ * recent probe found in a render / warp stack (0, 0 before the first probe).  Any pointer may be null.  Diagnostics. */
+int nmi_last_content(nmi_ctx *ctx, int32_t *few_levels, int32_t *nr, int32_t *nw);
 
 #ifdef __cplusplus
 }

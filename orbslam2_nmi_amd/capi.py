@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = (
     "nmi_texture_destroy", "nmi_render_mesh", "nmi_stream_create", "nmi_stream_destroy",
     "nmi_stream_submit", "nmi_stream_wait", "nmi_stream_keep_ratings", "nmi_stream_copy_ratings", "nmi_key_pack", "nmi_key_unpack", "nmi_search_grid_rccl", "nmi_search_grid_block_rccl",
     "nmi_rccl_unique_id", "nmi_rccl_comm_init", "nmi_rccl_comm_destroy", "nmi_set_profiling", "nmi_last_kernel_ms",
-    "nmi_set_option", "nmi_copy_term_table", "nmi_abi_version", "nmi_error_string", "nmi_last_error_detail", "nmi_get_info",
+    "nmi_set_option", "nmi_copy_term_table", "nmi_abi_version", "nmi_error_string", "nmi_last_error_detail", "nmi_get_info", "nmi_last_content",
 )
 
 
@@ -116,6 +116,7 @@ def load_library(build_if_missing=False):
     lib.nmi_last_error_detail.argtypes = [vp]
     lib.nmi_last_error_detail.restype = C.c_char_p
     lib.nmi_get_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    lib.nmi_last_content.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     _lib = lib
     return lib
 
@@ -242,6 +243,7 @@ class NmiContext:
 
     OPT_HIST_VARIANT, OPT_PHASE_MASK, OPT_WORKGROUPS, OPT_RESULT_PATH, OPT_XCD_TILING, OPT_TILE_QUEUE = 1, 2, 3, 4, 5, 6
     OPT_SPLIT, OPT_WAIT_MODE, OPT_STAMPS, OPT_SPLIT_PIXELS, OPT_CLIP_QUEUE = 7, 8, 9, 10, 11
+    OPT_CONTENT_PATH, OPT_FEWLEVELS_BINS = 12, 13
 
     def set_option(self, option, value):
         self._check(self._lib.nmi_set_option(self._h, int(option), int(value)), "nmi_set_option")
@@ -261,6 +263,12 @@ class NmiContext:
         cu, wg, lds = C.c_int32(0), C.c_int32(0), C.c_int32(0)
         self._check(self._lib.nmi_get_info(self._h, C.byref(cu), C.byref(wg), C.byref(lds)), "nmi_get_info")
         return {"compute_units": cu.value, "workgroups_per_launch": wg.value, "lds_bytes": lds.value}
+
+    def last_content(self):
+        """How the most recent search was scored -> {"few_levels": bool, "nr": int, "nw": int} (see nmi_last_content)."""
+        f, r, w = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.nmi_last_content(self._h, C.byref(f), C.byref(r), C.byref(w)), "nmi_last_content")
+        return {"few_levels": bool(f.value), "nr": r.value, "nw": w.value}
 
     def term_table(self):
         """The per-count entropy-term table (NMI.cu:242-263 evaluated once per possible count) as numpy float32 [W*H+1]."""

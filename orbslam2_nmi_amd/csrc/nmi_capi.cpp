@@ -252,11 +252,49 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
         a.scratch = ctx->d_scratch;
     }
 #endif
+    // Few-levels path (nmi_fewlevels_kernel.hip).  The decision rests on what the most recent probe of a search's stacks
+    // found (frames and renders of consecutive searches look alike); it is only a matter of speed, because the probe that
+    // goes with every few-levels launch hands the search back to nmi_grid_kernel (gated launch below) when this
+    // search's stacks do not qualify.  While the hint says "ordinary content", every kProbeEvery-th search is probed.
+    bool few = false, probe_only = false;
+    const bool few_eligible = !parts && a.vec_ok && ctx->shift == 0 && ctx->hist_variant == 3 && ctx->phase_mask == 3 && !dbg_joint &&
+                              !dbg_h1 && !dbg_h2 && !dbg_sums && !ctx->pair_renders && !ctx->dbg_stamps && ctx->content_path != 0;
+    if (few_eligible) {
+        const unsigned long long posted = __atomic_load_n(ctx->level_post, __ATOMIC_ACQUIRE);
+        if ((uint32_t)(posted >> 32) != ctx->level_seen) {
+            ctx->level_seen = (uint32_t)(posted >> 32);
+            const uint32_t joint = (uint32_t)((posted >> 16) & 0xFFFFu) * (uint32_t)(posted & 0xFFFFu);
+            ctx->few_hint = joint > 0 && joint <= (uint32_t)ctx->fewlevels_bins;
+        }
+        few = ctx->content_path == 1 || ctx->few_hint;
+        probe_only = !few && (ctx->probe_clock++ % nmi_ctx::kProbeEvery) == 0;
+    }
+    if (few) {
+        const size_t need = (size_t)(S_local + Wn) * (size_t)ctx->npix;
+        if (need > ctx->rank_bytes) {
+            NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->d_rank_stacks) NMI_HIP_TRY(ctx, hipFree(ctx->d_rank_stacks));
+            ctx->d_rank_stacks = nullptr;
+            ctx->rank_bytes = 0;
+            NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_rank_stacks, need));
+            ctx->rank_bytes = need;
+        }
+        a.plan = ctx->d_plan;
+    }
     if (ctx->profiling) NMI_HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
-    if (parts)
+    if (few || probe_only)
+        NMI_HIP_TRY(ctx, nmi::launch_levels(render_stack, S_local, warp_stack, Wn, ctx->npix, ctx->d_plan, ctx->level_post, ++ctx->level_seq,
+                                            (uint32_t)ctx->fewlevels_bins, few, ctx->stream));
+    if (parts) {
         NMI_HIP_TRY(ctx, nmi::launch_split(a, parts, pix_parts, workgroups, p.use_bg != 0, ctx->stream));
-    else
+    } else if (few) {
+        NMI_HIP_TRY(ctx, nmi::launch_fewlevels(a, ctx->d_rank_stacks, ctx->d_rank_stacks + (size_t)S_local * ctx->npix, workgroups,
+                                               p.use_bg != 0, ctx->stream));
+        NMI_HIP_TRY(ctx, nmi::launch_grid_gated(a, workgroups, p.use_bg != 0, ctx->stream));
+    } else {
         NMI_HIP_TRY(ctx, nmi::launch_grid(a, workgroups, p.use_bg != 0, ctx->stream));
+    }
+    ctx->last_few = few ? 1 : 0;
     // accepted: commit the protocol state
     if (post) ++ctx->seq;
     if (post_score) ++ctx->pair_seq;
@@ -485,6 +523,11 @@ int nmi_create(const nmi_params *params, nmi_ctx **out_ctx)
         return fail(e, "hipHostGetDevicePointer(split error)");
     if ((e = hipHostMalloc((void **)&ctx->h_key, sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
         return fail(e, "hipHostMalloc(key)");
+    if ((e = hipHostMalloc((void **)&ctx->level_post, 64, hipHostMallocCoherent | hipHostMallocMapped)) != hipSuccess)
+        return fail(e, "hipHostMalloc(level post)");
+    *ctx->level_post = 0;
+    if ((e = hipMalloc((void **)&ctx->d_plan, sizeof(nmi::LevelPlan))) != hipSuccess) return fail(e, "hipMalloc(level plan)");
+    if ((e = hipMemsetAsync(ctx->d_plan, 0, sizeof(nmi::LevelPlan), ctx->stream)) != hipSuccess) return fail(e, "hipMemsetAsync(level plan)");
     if ((e = hipEventCreate(&ctx->ev_start)) != hipSuccess) return fail(e, "hipEventCreate");
     if ((e = hipEventCreate(&ctx->ev_stop)) != hipSuccess) return fail(e, "hipEventCreate");
     if ((e = nmi::launch_table(ctx->table, ctx->npix, ctx->stream)) != hipSuccess) return fail(e, "launch_table");
@@ -506,6 +549,9 @@ int nmi_destroy(nmi_ctx *ctx)
     if (ctx->d_pair_scores) (void)hipFree(ctx->d_pair_scores);
     if (ctx->d_blocks) (void)hipFree(ctx->d_blocks);
     if (ctx->h_split_error) (void)hipHostFree(ctx->h_split_error);
+    if (ctx->level_post) (void)hipHostFree(ctx->level_post);
+    if (ctx->d_plan) (void)hipFree(ctx->d_plan);
+    if (ctx->d_rank_stacks) (void)hipFree(ctx->d_rank_stacks);
     if (ctx->d_keys) (void)hipFree(ctx->d_keys);
     if (ctx->d_done) (void)hipFree(ctx->d_done);
     if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
@@ -596,6 +642,16 @@ int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value)
         if (value < 0) return NMI_ERR_INVALID_ARGUMENT;
         ctx->clip_queue_limit = (unsigned long long)value;
         return NMI_OK;
+    case NMI_OPT_CONTENT_PATH:
+        if (value < -1 || value > 1) return NMI_ERR_INVALID_ARGUMENT;
+        ctx->content_path = (int)value;
+        ctx->few_hint = false;
+        ctx->probe_clock = 0;
+        return NMI_OK;
+    case NMI_OPT_FEWLEVELS_BINS:
+        if (value < 1 || value > nmi::fewlevels_max_joint()) return NMI_ERR_INVALID_ARGUMENT;
+        ctx->fewlevels_bins = (int)value;
+        return NMI_OK;
     case NMI_OPT_WORKGROUPS:
         if (value < 0 || value > (1 << 20)) return NMI_ERR_INVALID_ARGUMENT;
         ctx->workgroups = (int)value;
@@ -629,6 +685,20 @@ int nmi_get_info(nmi_ctx *ctx, int32_t *compute_units, int32_t *workgroups_per_l
     if (compute_units) *compute_units = ctx->compute_units;
     if (workgroups_per_launch) *workgroups_per_launch = ctx->workgroups > 0 ? ctx->workgroups : ctx->compute_units;
     if (lds_bytes) *lds_bytes = nmi::grid_kernel_lds_bytes();
+    return NMI_OK;
+}
+
+int nmi_last_content(nmi_ctx *ctx, int32_t *few_levels, int32_t *nr, int32_t *nw)
+{
+    if (!ctx) return NMI_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(ctx->device);
+    NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned long long posted = __atomic_load_n(ctx->level_post, __ATOMIC_ACQUIRE);
+    const int32_t r = (int32_t)((posted >> 16) & 0xFFFFu), w = (int32_t)(posted & 0xFFFFu);
+    if (nr) *nr = r;
+    if (nw) *nw = w;
+    // a few-levels launch carries its own probe, so the post is about that very search
+    if (few_levels) *few_levels = (ctx->last_few && r > 0 && w > 0 && (int64_t)r * w <= ctx->fewlevels_bins) ? 1 : 0;
     return NMI_OK;
 }
 

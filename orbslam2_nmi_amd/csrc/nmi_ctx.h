@@ -74,6 +74,20 @@ struct nmi_ctx {
     const uint8_t *const *pair_renders = nullptr, *const *pair_warps = nullptr;            // device views for the launch being enqueued
     const uint8_t *const *pair_renders_host = nullptr, *const *pair_warps_host = nullptr;  // the caller's arrays (alignment check)
     int split_pixels = -1;                // NMI_OPT_SPLIT_PIXELS: -1 automatic, 1 / 2 / 4
+    // Few-levels path (nmi_fewlevels_kernel.hip): which kernels score a search is decided from what the last probe of
+    // the stacks found, posted by the device to *level_post = probe number << 32 | nr << 16 | nw.
+    nmi::LevelPlan *d_plan = nullptr;
+    unsigned long long *level_post = nullptr;  // pinned, fine-grained
+    uint32_t level_seq = 0;               // probes enqueued so far
+    uint32_t level_seen = 0;              // number of the probe the hint below comes from
+    bool few_hint = false;                // the last probe seen found nr * nw <= fewlevels_bins
+    int content_path = -1;                // NMI_OPT_CONTENT_PATH: -1 automatic (hint), 0 nmi_grid_kernel only, 1 few-levels first
+    int fewlevels_bins = 4096;            // NMI_OPT_FEWLEVELS_BINS: largest nr * nw sent down the few-levels path
+    uint64_t probe_clock = 0;             // eligible searches since the context was created (automatic mode probes every kProbeEvery)
+    static constexpr int kProbeEvery = 32;
+    uint8_t *d_rank_stacks = nullptr;     // rank images of the search in flight: renders, then warps
+    size_t rank_bytes = 0;
+    int last_few = 0;                     // the most recent launch went down the few-levels path (it may have fallen back)
     unsigned long long *dbg_stamps = nullptr;  // NMI_OPT_STAMPS
     int split_mode = -1;                  // NMI_OPT_SPLIT: -1 automatic, 0 never, 2 / 4 / 8 parts whenever the grid fits
     uint32_t *d_zbuf = nullptr;           // depth|colour anchor buffers of the point-cloud renderer (padded, per view)

@@ -16,6 +16,18 @@ struct Mailbox {
     unsigned long long pad;
 };
 
+// What nmi_levels_kernel found in the two stacks of a search (nmi_fewlevels_kernel.hip); lives in device memory.
+struct LevelPlan {
+    uint32_t use;             // 1: nmi_fewlevels_kernel scores this search, 0: nmi_grid_kernel (its gated launch) does
+    uint32_t nr, nw;          // distinct intensities in the render stack / in the warp stack
+    uint32_t copies;          // interleaved copies of each counter (8, 16 or 32)
+    uint32_t ticket;          // probe workgroups that have merged their masks (left 0)
+    uint32_t pad[3];
+    uint32_t mask[2][8];      // presence bits being merged by a probe (left 0)
+    uint8_t rank_r[256], rank_w[256];    // intensity -> rank among the intensities present (0 where absent)
+    uint8_t level_r[256], level_w[256];  // rank -> intensity
+};
+
 struct GridArgs {
     const uint8_t *render_stack;  // [S_local][H][W]
     const uint8_t *warp_stack;    // [Wn][H][W]
@@ -37,7 +49,12 @@ struct GridArgs {
     int mode;                     // NMI_MODE_*_
     int flip;                     // render stored bottom-up (NMI.cu:82)
     const float *table;           // [npix + 1] per-count entropy terms
-    uint32_t *scratch;            // pipelined kernel: [workgroups][2][32768] drained packed counters
+    // One slot, two users that never meet (nmi_grid_kernel sits at its register cap and its allocation shifts with the
+    // offsets and the size of this struct, so the struct keeps both):
+    union {
+        uint32_t *scratch;        // pipelined kernel (ablation build): [workgroups][2][32768] drained packed counters
+        const LevelPlan *plan;    // few-levels path: the plan of this search; the gated nmi_grid_kernel runs iff plan->use == 0
+    };
     const int *order;             // [S_local * Wn] candidate visited at each ordinal (XCD-aware tiling), or nullptr = identity
     float *ratings;               // [Wn][S_local] or nullptr
     unsigned long long *key;      // packed arg-max slot of this launch (zero on entry)
@@ -74,6 +91,17 @@ inline void set_geometry(GridArgs &a, int width, int height, const void *render_
 
 hipError_t launch_table(float *table, int npix, hipStream_t stream);
 hipError_t launch_grid(const GridArgs &a, int workgroups, bool use_bg, hipStream_t stream);
+// The same kernel as the fallback behind launch_fewlevels: it returns at once unless a.plan->use == 0.  256 bins only.
+hipError_t launch_grid_gated(const GridArgs &a, int workgroups, bool use_bg, hipStream_t stream);
+
+// Few-levels path (nmi_fewlevels_kernel.hip).  launch_levels probes the stacks (16-byte aligned, npix % 16 == 0) and
+// writes *plan (use = commit && nr * nw <= max_joint) and, if given, the pinned word *post = seq << 32 | nr << 16 | nw.
+// launch_fewlevels = rank images + scoring kernel; both do nothing when plan->use == 0.
+hipError_t launch_levels(const uint8_t *render_stack, int S, const uint8_t *warp_stack, int Wn, int npix, LevelPlan *plan,
+                         unsigned long long *post, uint32_t seq, uint32_t max_joint, bool commit, hipStream_t stream);
+hipError_t launch_fewlevels(const GridArgs &a, uint8_t *rank_renders, uint8_t *rank_warps, int workgroups, bool use_bg,
+                            hipStream_t stream);
+int fewlevels_max_joint();  // largest nr * nw the scoring kernel takes
 bool ablation_variants_built();  // HIST variants 0 / 2 / 4 compiled in (-DNMI_BUILD_ABLATIONS)?
 
 // Split form for grids with fewer candidates than compute units (nmi_split_kernel.hip): K workgroups per candidate, each

@@ -553,10 +553,23 @@ __device__ __forceinline__ void exact_candidate(Lds &lds, const GridArgs &a, int
 // Two barriers per candidate: B1 histogram -> decode, B2 decode -> (wavefront 0: three final trees +
 // score + arg-max) || (all other wavefronts: next candidate's histogram phase).  The small per-candidate
 // state that the two sides would share is double-buffered by candidate parity.
+//
+// nmi_kernels_gated.hip compiles this file a second time with NMI_GRID_KERNEL_GATED defined: the same kernel under the
+// name nmi_grid_kernel_gated, which returns at once unless the few-levels kernels enqueued before it handed the search
+// back (plan->use == 0, nmi_fewlevels_kernel.hip).  A second translation unit rather than a template parameter because
+// this kernel sits at its register cap: the mere presence of more instantiations in this unit changed its allocation.
+#ifdef NMI_GRID_KERNEL_GATED
+#define NMI_GRID_KERNEL_NAME nmi_grid_kernel_gated
+#else
+#define NMI_GRID_KERNEL_NAME nmi_grid_kernel
+#endif
 template <bool BG, bool SHIFTED, int HIST>
-__global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
+__global__ __launch_bounds__(NMI_BLOCK_THREADS) void NMI_GRID_KERNEL_NAME(GridArgs a)
 {
     __shared__ Lds lds;
+#ifdef NMI_GRID_KERNEL_GATED
+    if (a.plan->use != 0u) return;
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -642,6 +655,19 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel(GridArgs a)
 
     if (tid == 0 && !(a.phase_mask & 16)) publish_winner(a, prev_key);  // bit 4: timing experiment without the protocol (no result)
 }
+
+#ifdef NMI_GRID_KERNEL_GATED
+// The fallback launch behind launch_fewlevels: 256 bins, default histogram variant.
+hipError_t launch_grid_gated(const GridArgs &a, int workgroups, bool use_bg, hipStream_t stream)
+{
+    if (a.shift != 0 || a.hist_variant != 3 || !a.plan) return hipErrorInvalidValue;
+    if (use_bg)
+        hipLaunchKernelGGL((nmi_grid_kernel_gated<true, false, 3>), dim3(workgroups), dim3(kBlock), 0, stream, a);
+    else  // the wrap detector of HIST = 3 needs the expected pixel count, which is W*H only with BG on
+        hipLaunchKernelGGL((nmi_grid_kernel_gated<false, false, 1>), dim3(workgroups), dim3(kBlock), 0, stream, a);
+    return hipGetLastError();
+}
+#else  // everything below belongs to the primary translation unit only
 
 #ifdef NMI_BUILD_ABLATIONS  // experiments kept for tools/ablate.py; not part of the shipped library
 // ---------------------------------------------------------------------------------------------------------
@@ -944,5 +970,7 @@ bool ablation_variants_built()
 
 int grid_kernel_lds_bytes() { return (int)sizeof(Lds); }
 size_t grid_kernel_scratch_bytes(int workgroups) { return (size_t)workgroups * 2 * kWords * sizeof(uint32_t); }
+
+#endif  // !NMI_GRID_KERNEL_GATED
 
 }  // namespace nmi

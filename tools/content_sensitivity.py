@@ -34,6 +34,8 @@ def flat_top(a, frac, value):
 cases = {
     "default (smooth scene + noise)": (wl["render_stack"], wl["warp_stack"]),
     "uniform noise": (rng.integers(0, 256, (S, H, W), dtype=np.uint8), rng.integers(0, 256, (Wn, H, W), dtype=np.uint8)),
+    "posterised to 64 levels": (posterise(wl["render_stack"], 64), posterise(wl["warp_stack"], 64)),
+    "posterised to 32 levels": (posterise(wl["render_stack"], 32), posterise(wl["warp_stack"], 32)),
     "posterised to 16 levels": (posterise(wl["render_stack"], 16), posterise(wl["warp_stack"], 16)),
     "posterised to 4 levels": (posterise(wl["render_stack"], 4), posterise(wl["warp_stack"], 4)),
     # rows are bottom-up in the render and top-down in the warp: flatten the same scene rows in both
@@ -51,12 +53,14 @@ for name, (rs_h, ws_h) in cases.items():
     rs, ws = torch.from_numpy(np.ascontiguousarray(rs_h)).cuda(), torch.from_numpy(np.ascontiguousarray(ws_h)).cuda()
     ratings = torch.empty((Wn, S), dtype=torch.float32, device="cuda")
     t = []
-    for i in range(12):
+    for i in range(48):  # default options: the path follows the content within 32 searches (NMI_OPT_CONTENT_PATH -1)
         r = ctx.search_grid(rs, ws, ratings=ratings)
-        if i >= 2:
-            t.append(ctx.last_kernel_ms() * 1e3)
-    us = float(np.median(t))
-    out.append({"content": name, "kernel_us": round(us, 1), "evals_per_s": round(S * Wn / us * 1e6)})
-    print(f"{name:42s} {us:8.1f} us  {S * Wn / us:6.2f} M evals/s", flush=True)
+        t.append(ctx.last_kernel_ms() * 1e3)
+    us, first = float(np.median(t[-10:])), float(t[0])
+    info = ctx.last_content()
+    path = "few-levels (%d x %d)" % (info["nr"], info["nw"]) if info["few_levels"] else "general"
+    out.append({"content": name, "kernel_us": round(us, 1), "evals_per_s": round(S * Wn / us * 1e6), "path": path,
+                "first_search_us": round(first, 1)})
+    print(f"{name:42s} {us:8.1f} us  {S * Wn / us:6.2f} M evals/s   {path}   (first search after the change of content {first:.1f} us)", flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "content_sensitivity.json"), "w"), indent=1)
