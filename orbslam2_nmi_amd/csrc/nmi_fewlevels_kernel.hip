@@ -406,7 +406,9 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_fewlevels_kernel(GridAr
 hipError_t launch_levels(const uint8_t *render_stack, int S, const uint8_t *warp_stack, int Wn, int npix, LevelPlan *plan,
                          unsigned long long *post, uint32_t seq, uint32_t max_joint, bool commit, hipStream_t stream)
 {
-    const int slices = 4;  // measured 1 / 2 / 3 / 4 / 8 slices per image at 640x480: - / 11.8 / 10.7 / 11.0 / 13.3 us for 54 images
+    // measured with 2 / 3 / 4 / 8 slices per image at 640x480: 11.8 / 10.7 / 11.0 / 13.3 us for 54 images, of which 6.9 us
+    // are there without the scan (launch, 32 KiB of LDS cleared, merge, ticket, plan, kernel-end cache maintenance)
+    const int slices = 4;
     hipLaunchKernelGGL(nmi_levels_kernel, dim3((S + Wn) * slices), dim3(kProbeBlock), 0, stream, render_stack, S, warp_stack, Wn, npix, slices,
                        plan, post, seq, max_joint, commit ? 1 : 0);
     return hipGetLastError();

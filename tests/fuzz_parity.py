@@ -2,7 +2,8 @@
 """Randomised parity campaign on the GPU: grids of random shape and content against the C oracle.
 
 Content is drawn to reach every branch of the histogram phase: textured, uniform noise, posterised (bins above 65,535),
-flat bands / blocks in one or both stacks (folding, side counters, more flat pairs than side counters), zero regions
+flat bands / blocks in one or both stacks (folding, side counters, more flat pairs than side counters), quantised to a
+random set of levels (kinds=7; with NMI_OPT_SPLIT 0 and NMI_OPT_CONTENT_PATH 1 these go down the few-levels path), zero regions
 with the background rule off, reduced bin counts, both render orientations.  For every case the whole rating table must
 EQUAL the oracle's (rounded term mode: same fp32 operations in the same order) and the winner (index and score) must be
 the oracle's; the libm-mode oracle (log2f as written) is kept as a <= 1e-5 cross-check.  Test infrastructure (it calls the oracle):
@@ -20,7 +21,7 @@ from oracle import binding as ob
 SHAPES = [(640, 480), (848, 480), (320, 240), (960, 540), (64, 48), (100, 75), (333, 100), (32, 2), (1280, 720)]
 
 
-def run(cases=200, seed=1, verbose=True, options=None):
+def run(cases=200, seed=1, verbose=True, options=None, kinds=6):
     rng = np.random.default_rng(seed)
 
     def content(kind, n, h, w):
@@ -32,6 +33,10 @@ def run(cases=200, seed=1, verbose=True, options=None):
         if kind == 2:  # posterised
             lv = int(rng.choice([2, 4, 16]))
             return (rng.integers(0, lv, (n, h, w)) * (255 // (lv - 1))).astype(np.uint8)
+        if kind == 6:  # textured content quantised to 2..70 unevenly spaced levels (the few-levels path's home ground)
+            lv = int(rng.integers(2, 71))
+            levels = np.sort(rng.choice(256, lv, replace=False)).astype(np.uint8)
+            return levels[(content(1, n, h, w).astype(np.int32) * lv) >> 8]
         a = content(int(rng.integers(0, 2)), n, h, w)
         if kind == 3:  # horizontal flat bands
             for i in range(n):
@@ -52,7 +57,7 @@ def run(cases=200, seed=1, verbose=True, options=None):
     for c in range(cases):
         w, h = SHAPES[int(rng.integers(len(SHAPES)))]
         S, Wn = int(rng.integers(1, 9)), int(rng.integers(1, 9))
-        kr, kw = int(rng.integers(0, 6)), int(rng.integers(0, 6))
+        kr, kw = int(rng.integers(0, kinds)), int(rng.integers(0, kinds))
         rs, ws = content(kr, S, h, w), content(kw, Wn, h, w)
         if rng.random() < 0.3 and kr >= 3:  # the same flat rows in both stacks: flat-over-flat pairs
             ws[:, : h // 3] = rs[0, : h // 3][None] if rng.random() < 0.5 else 255

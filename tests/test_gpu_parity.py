@@ -752,6 +752,10 @@ def test_fuzz_campaign_against_the_oracle(nmi):
     # the same campaign's first cases through the one-workgroup-per-candidate kernel only (the grids above are small
     # enough that the automatic selection scores most of them with the split kernel)
     assert fuzz_parity.run(60, seed=11, verbose=False, options={nmi.NmiContext.OPT_SPLIT: 0}) == 0.0
+    # few-levels path first for every case (quantised content among the kinds): it scores what qualifies and hands the
+    # rest back to the general kernel on the device
+    C = nmi.NmiContext
+    assert fuzz_parity.run(120, seed=12, verbose=False, options={C.OPT_SPLIT: 0, C.OPT_CONTENT_PATH: 1}, kinds=7) == 0.0
 
 
 def test_two_contexts_from_two_threads(nmi):
