@@ -386,6 +386,10 @@ __device__ __forceinline__ void apply_wraps(const Lds &lds, int par, uint32_t no
 // n >= 16 of NMI.cu:276-284 then pairs two values of the same lane and the steps n = 8..1 are DPP
 // shifts inside the 16-lane row: no LDS traffic besides reading (and clearing) the counters.
 // Odd DPP rows start at k = 1 so that the two rows of a 32-lane LDS access group hit disjoint banks.
+// ZERO0 (background rule off, NMI.cu:85: a pixel counts only if both intensities are non-zero): the histogram phase
+// has counted every pixel -- the skipped ones are exactly row 0 and column 0 of the joint histogram, which are cleared
+// here, after they have entered the wrap detector's total.
+template <bool ZERO0 = false>
 __device__ __forceinline__ void decode_phase(Lds &lds, int par, const GridArgs &a, int wave, int lane)
 {
     const uint32_t novf = lds.ovf_n[par] < (uint32_t)kOvfCap ? lds.ovf_n[par] : (uint32_t)kOvfCap;
@@ -432,6 +436,17 @@ __device__ __forceinline__ void decode_phase(Lds &lds, int par, const GridArgs &
             }
         }
         uint32_t rsum = 0, cmax = 0;
+        if (ZERO0) {
+            uint32_t raw = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) raw += lo[k] + hi[k];
+            wave_total += row_sum_16(raw);
+            if (i == 0) lo[o ? 7 : 0] = 0;  // the bin d2 = 0 of this row
+            if (d1 == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) lo[k] = hi[k] = 0;
+            }
+        }
         float tl[8], th[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -451,7 +466,7 @@ __device__ __forceinline__ void decode_phase(Lds &lds, int par, const GridArgs &
             }
         }
         rsum = row_sum_16(rsum);
-        wave_total += rsum;
+        if (!ZERO0) wave_total += rsum;
         const float x = row_tree_16(lane_tree_16(tl, th));
         if (i == 0) {
             lds.hist_render[d1] = rsum;
@@ -521,7 +536,7 @@ __device__ __forceinline__ void final_phase(Lds &lds, const GridArgs &a, int lan
 // AFTER their hot loop, never inside it: inlined into the hot loop it cost ~10 % there (spills, code size), and as a
 // real function call inside the loop ~25 %.  Uses the parity-0 event list / total and leaves them, hist_warped and
 // the joint counters zero.
-template <bool SHIFTED>
+template <bool SHIFTED, bool BG = true>
 __device__ __forceinline__ void exact_candidate(Lds &lds, const GridArgs &a, int tid, int p, unsigned long long &prev_key)
 {
     const int lane = tid & 63, wave = tid >> 6;
@@ -529,7 +544,7 @@ __device__ __forceinline__ void exact_candidate(Lds &lds, const GridArgs &a, int
     __syncthreads();  // wavefront 0 may still be finishing the previous candidate's final phase (it resets shared state)
     histogram_phase<true, SHIFTED, 1, kBlock>(lds, 0, a, a.render_stack + (size_t)s * a.npix, a.warp_stack + (size_t)w * a.npix, tid);
     __syncthreads();
-    decode_phase(lds, 0, a, wave, lane);
+    decode_phase<!BG>(lds, 0, a, wave, lane);
     __syncthreads();
     if (wave == 0) {
         final_phase(lds, a, lane, p, w, s, prev_key);
@@ -575,6 +590,12 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void NMI_GRID_KERNEL_NAME(GridAr
     const int wave = tid >> 6;
     constexpr bool kOptimistic = HIST == 3;
     constexpr int kFirst = kOptimistic ? 2 : HIST;
+    // Background rule off (NMI.cu:85) on the optimistic path: every pixel is counted, so that the wrap detector knows the
+    // expected total (W*H), and decode_phase clears the row and the column of intensity 0 -- the skipped pixels.  Only
+    // with 256 bins: the rule looks at the intensity before the shift, and bin 0 of a shifted histogram also holds
+    // intensities 1 .. 2^shift - 1 (launch_grid sends BG off + shift to the exact path, HIST = 1).
+    constexpr bool kZero0 = !BG && kOptimistic && !SHIFTED;
+    constexpr bool kCountAll = BG || kZero0;
 
     if (blockIdx.x == 0 && tid == 0 && a.reset_key) *a.reset_key = 0ull;  // next launch's slot; idle during this one
     // The LDS copy of the term table is first needed by the first decode phase: fetch it now, park it in
@@ -611,9 +632,9 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void NMI_GRID_KERNEL_NAME(GridAr
 
         if (a.phase_mask & 1) {
             if (a.phase_mask & 8) {  // ablation: only half of the wavefronts take part in the histogram phase
-                if (wave < kWaves / 2) histogram_phase<BG, SHIFTED, kFirst, kBlock / 2>(lds, par, a, render, warped, tid);
+                if (wave < kWaves / 2) histogram_phase<kCountAll, SHIFTED, kFirst, kBlock / 2>(lds, par, a, render, warped, tid);
             } else
-                histogram_phase<BG, SHIFTED, kFirst, kBlock>(lds, par, a, render, warped, tid);
+                histogram_phase<kCountAll, SHIFTED, kFirst, kBlock>(lds, par, a, render, warped, tid);
         }
         if (table_pending) {
 #pragma unroll
@@ -621,7 +642,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void NMI_GRID_KERNEL_NAME(GridAr
             table_pending = false;
         }
         __syncthreads();  // B1
-        if (a.phase_mask & 2) decode_phase(lds, par, a, wave, lane);
+        if (a.phase_mask & 2) decode_phase<kZero0>(lds, par, a, wave, lane);
         __syncthreads();  // B2
         if (kOptimistic && (a.phase_mask & 3) == 3 && lds.total[par] != (uint32_t)a.npix) {
             // Some counter wrapped (workgroup-uniform, rare).  This candidate and, since the same frame and renders
@@ -650,7 +671,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void NMI_GRID_KERNEL_NAME(GridAr
         if (tid < 2) lds.total[tid] = lds.ovf_n[tid] = 0;
         if (tid < 2 * kSide) (&lds.side_key[0][0])[tid] = (&lds.side_cnt[0][0])[tid] = 0;
         __syncthreads();
-        for (int o = exact_from; o < total; o += gridDim.x) exact_candidate<SHIFTED>(lds, a, tid, candidate_at(a, o), prev_key);
+        for (int o = exact_from; o < total; o += gridDim.x) exact_candidate<SHIFTED, !kZero0>(lds, a, tid, candidate_at(a, o), prev_key);
     }
 
     if (tid == 0 && !(a.phase_mask & 16)) publish_winner(a, prev_key);  // bit 4: timing experiment without the protocol (no result)
@@ -663,8 +684,8 @@ hipError_t launch_grid_gated(const GridArgs &a, int workgroups, bool use_bg, hip
     if (a.shift != 0 || a.hist_variant != 3 || !a.plan) return hipErrorInvalidValue;
     if (use_bg)
         hipLaunchKernelGGL((nmi_grid_kernel_gated<true, false, 3>), dim3(workgroups), dim3(kBlock), 0, stream, a);
-    else  // the wrap detector of HIST = 3 needs the expected pixel count, which is W*H only with BG on
-        hipLaunchKernelGGL((nmi_grid_kernel_gated<false, false, 1>), dim3(workgroups), dim3(kBlock), 0, stream, a);
+    else
+        hipLaunchKernelGGL((nmi_grid_kernel_gated<false, false, 3>), dim3(workgroups), dim3(kBlock), 0, stream, a);
     return hipGetLastError();
 }
 #else  // everything below belongs to the primary translation unit only
@@ -931,8 +952,9 @@ hipError_t launch_grid(const GridArgs &a, int workgroups, bool use_bg, hipStream
     switch (a.hist_variant) {
     case 1: launch_hist<1>(a, grid, block, use_bg, stream); break;
     case 3:
-        // The wrap detector of HIST = 3 needs the expected pixel count, which is W*H only with BG on.
-        if (use_bg)
+        // The wrap detector of HIST = 3 needs the expected pixel count: W*H with BG on, and with BG off at 256 bins (the
+        // kernel then counts every pixel and clears row / column 0 afterwards); BG off with fewer bins takes the exact path.
+        if (use_bg || a.shift == 0)
             launch_hist<3>(a, grid, block, use_bg, stream);
         else
             launch_hist<1>(a, grid, block, use_bg, stream);
