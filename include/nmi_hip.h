@@ -320,7 +320,8 @@ int nmi_last_kernel_ms(nmi_ctx *ctx, float *h_ms);
 #define NMI_OPT_CONTENT_PATH 12 /* frames with few distinct intensities (posterised, thresholded, quantised): -1 (default)
                                   automatic -- every 32nd search is probed for the number of distinct intensities in its two
                                   stacks (nr, nw), and while nr * nw <= NMI_OPT_FEWLEVELS_BINS searches go down the few-levels
-                                  path (rank images + 32-bit replicated counters; csrc/nmi_fewlevels_kernel.hip); 0: never;
+                                  path (rank images + 32-bit replicated counters; csrc/nmi_fewlevels_kernel.hip; with fewer than
+                                  256 bins the count is of bins, and the background rule must be on); 0: never;
                                   1: always try it first.  Every few-levels search probes its own stacks and falls back to
                                   the general kernel on the device when they do not qualify: results never depend on it. */
 #define NMI_OPT_FEWLEVELS_BINS 13 /* largest nr * nw sent down the few-levels path (1..4096, default 4096) */

@@ -257,7 +257,7 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     // goes with every few-levels launch hands the search back to nmi_grid_kernel (gated launch below) when this
     // search's stacks do not qualify.  While the hint says "ordinary content", every kProbeEvery-th search is probed.
     bool few = false, probe_only = false;
-    const bool few_eligible = !parts && a.vec_ok && ctx->shift == 0 && ctx->hist_variant == 3 && ctx->phase_mask == 3 && !dbg_joint &&
+    const bool few_eligible = !parts && a.vec_ok && (ctx->shift == 0 || p.use_bg) && ctx->hist_variant == 3 && ctx->phase_mask == 3 && !dbg_joint &&
                               !dbg_h1 && !dbg_h2 && !dbg_sums && !ctx->pair_renders && !ctx->dbg_stamps && ctx->content_path != 0;
     if (few_eligible) {
         const unsigned long long posted = __atomic_load_n(ctx->level_post, __ATOMIC_ACQUIRE);
@@ -283,7 +283,7 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     }
     if (ctx->profiling) NMI_HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     if (few || probe_only)
-        NMI_HIP_TRY(ctx, nmi::launch_levels(render_stack, S_local, warp_stack, Wn, ctx->npix, ctx->d_plan, ctx->level_post, ++ctx->level_seq,
+        NMI_HIP_TRY(ctx, nmi::launch_levels(render_stack, S_local, warp_stack, Wn, ctx->npix, ctx->shift, ctx->d_plan, ctx->level_post, ++ctx->level_seq,
                                             (uint32_t)ctx->fewlevels_bins, few, ctx->stream));
     if (parts) {
         NMI_HIP_TRY(ctx, nmi::launch_split(a, parts, pix_parts, workgroups, p.use_bg != 0, ctx->stream));

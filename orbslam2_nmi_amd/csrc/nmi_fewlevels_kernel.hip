@@ -51,7 +51,7 @@ constexpr int kProbeBlock = 1024;
 __global__ __launch_bounds__(kProbeBlock) void nmi_levels_kernel(const uint8_t *__restrict__ render_stack, int S,
                                                           const uint8_t *__restrict__ warp_stack, int Wn, int npix, int slices,
                                                           LevelPlan *plan, unsigned long long *post, uint32_t seq,
-                                                          uint32_t max_joint, int commit)
+                                                          uint32_t max_joint, int commit, int shift)
 {
     __shared__ uint32_t present[kBins * kProbeCopies];
     __shared__ uint32_t am_last;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kProbeBlock) void nmi_levels_kernel(const uint8_t *
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) mine[((d[q] >> (8 * j)) & 0xFFu) * kProbeCopies] = 1;  // fire and forget
+            for (int j = 0; j < 4; ++j) mine[(((d[q] >> (8 * j)) & 0xFFu) >> shift) * kProbeCopies] = 1;  // fire and forget
         }
     };
     // four loads in flight per lane; out-of-range chunks re-read the slice's last one
@@ -127,23 +127,26 @@ __global__ __launch_bounds__(kProbeBlock) void nmi_levels_kernel(const uint8_t *
         __hip_atomic_store(src, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next probe
     }
     __syncthreads();
+    // With fewer than 256 bins (intensity >> shift, NMI.cu:46-48 via the bin count) the masks are over bins; every raw
+    // intensity gets the rank of its bin, and level[] holds bins.
     uint32_t n[2];
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
+        const uint32_t bin = (uint32_t)(tid & 255) >> shift;
         uint32_t below = 0, all = 0;
         for (int k = 0; k < 8; ++k) {
             const uint32_t w = mk[st][k];
             all += __popc(w);
-            if (k < ((tid & 255) >> 5)) below += __popc(w);
+            if (k < (int)(bin >> 5)) below += __popc(w);
         }
-        const uint32_t mine = mk[st][(tid & 255) >> 5];
-        below += __popc(mine & ((1u << (tid & 31)) - 1u));
-        const bool here = (mine >> (tid & 31)) & 1u;
+        const uint32_t mine = mk[st][bin >> 5];
+        below += __popc(mine & ((1u << (bin & 31)) - 1u));
+        const bool here = (mine >> (bin & 31)) & 1u;
         uint8_t *rank = st == 0 ? plan->rank_r : plan->rank_w;
         uint8_t *level = st == 0 ? plan->level_r : plan->level_w;
         if (tid < kBins) {
             rank[tid] = here ? (uint8_t)below : (uint8_t)0;
-            if (here) level[below] = (uint8_t)tid;
+            if (here && (uint32_t)tid == (bin << shift)) level[below] = (uint8_t)bin;
         }
         n[st] = all;
     }
@@ -280,12 +283,14 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_fewlevels_kernel(GridAr
         for (int i = tid; i < kCounterWords / 4; i += kBlock) c4[i] = z;
     }
     if (tid < kBins) {
-        // rank_w: intensity -> rank, or kAbsent (rank_w alone cannot tell rank 0 from "does not occur")
-        const uint32_t rk = plan->rank_w[tid];
-        lds.rank_w[tid] = (rk < nw && plan->level_w[rk] == (uint8_t)tid) ? (uint16_t)rk : (uint16_t)kAbsent;
+        // rank_w: bin -> rank, or kAbsent (the plan's table is by raw intensity and cannot tell rank 0 from "does not occur")
+        const uint32_t raw = (uint32_t)tid << a.shift;
+        const uint32_t rk = raw < (uint32_t)kBins ? plan->rank_w[raw] : 0u;
+        lds.rank_w[tid] = (raw < (uint32_t)kBins && rk < nw && plan->level_w[rk] == (uint8_t)tid) ? (uint16_t)rk : (uint16_t)kAbsent;
         lds.level_r[tid] = (uint32_t)tid < nr ? plan->level_r[tid] : (uint8_t)0;
     }
     // !BG (NMI.cu:85): pixels with render or frame intensity 0 are not counted = row / column of intensity 0 cleared
+    // (256 bins only: with fewer, bin 0 also holds intensities the rule keeps; the host then does not come here)
     const bool zero_r0 = !BG && nr > 0 && plan->level_r[0] == 0, zero_w0 = !BG && nw > 0 && plan->level_w[0] == 0;
     __syncthreads();
 
@@ -403,14 +408,14 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_fewlevels_kernel(GridAr
     if (tid == 0) publish_winner(a, prev_key);
 }
 
-hipError_t launch_levels(const uint8_t *render_stack, int S, const uint8_t *warp_stack, int Wn, int npix, LevelPlan *plan,
+hipError_t launch_levels(const uint8_t *render_stack, int S, const uint8_t *warp_stack, int Wn, int npix, int shift, LevelPlan *plan,
                          unsigned long long *post, uint32_t seq, uint32_t max_joint, bool commit, hipStream_t stream)
 {
     // measured with 2 / 3 / 4 / 8 slices per image at 640x480: 11.8 / 10.7 / 11.0 / 13.3 us for 54 images, of which 6.9 us
     // are there without the scan (launch, 32 KiB of LDS cleared, merge, ticket, plan, kernel-end cache maintenance)
     const int slices = 4;
     hipLaunchKernelGGL(nmi_levels_kernel, dim3((S + Wn) * slices), dim3(kProbeBlock), 0, stream, render_stack, S, warp_stack, Wn, npix, slices,
-                       plan, post, seq, max_joint, commit ? 1 : 0);
+                       plan, post, seq, max_joint, commit ? 1 : 0, shift);
     return hipGetLastError();
 }
 

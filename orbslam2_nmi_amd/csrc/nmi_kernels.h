@@ -19,13 +19,13 @@ struct Mailbox {
 // What nmi_levels_kernel found in the two stacks of a search (nmi_fewlevels_kernel.hip); lives in device memory.
 struct LevelPlan {
     uint32_t use;             // 1: nmi_fewlevels_kernel scores this search, 0: nmi_grid_kernel (its gated launch) does
-    uint32_t nr, nw;          // distinct intensities in the render stack / in the warp stack
+    uint32_t nr, nw;          // distinct intensities (bins, with fewer than 256 of them) in the render stack / in the warp stack
     uint32_t copies;          // interleaved copies of each counter (8, 16 or 32)
     uint32_t ticket;          // probe workgroups that have merged their masks (left 0)
     uint32_t pad[3];
     uint32_t mask[2][8];      // presence bits being merged by a probe (left 0)
-    uint8_t rank_r[256], rank_w[256];    // intensity -> rank among the intensities present (0 where absent)
-    uint8_t level_r[256], level_w[256];  // rank -> intensity
+    uint8_t rank_r[256], rank_w[256];    // intensity -> rank of its bin among the bins present (0 where absent)
+    uint8_t level_r[256], level_w[256];  // rank -> bin
 };
 
 struct GridArgs {
@@ -91,13 +91,14 @@ inline void set_geometry(GridArgs &a, int width, int height, const void *render_
 
 hipError_t launch_table(float *table, int npix, hipStream_t stream);
 hipError_t launch_grid(const GridArgs &a, int workgroups, bool use_bg, hipStream_t stream);
-// The same kernel as the fallback behind launch_fewlevels: it returns at once unless a.plan->use == 0.  256 bins only.
+// The same kernel as the fallback behind launch_fewlevels: it returns at once unless a.plan->use == 0.  Fewer than 256 bins
+// only with the background rule on.
 hipError_t launch_grid_gated(const GridArgs &a, int workgroups, bool use_bg, hipStream_t stream);
 
 // Few-levels path (nmi_fewlevels_kernel.hip).  launch_levels probes the stacks (16-byte aligned, npix % 16 == 0) and
 // writes *plan (use = commit && nr * nw <= max_joint) and, if given, the pinned word *post = seq << 32 | nr << 16 | nw.
 // launch_fewlevels = rank images + scoring kernel; both do nothing when plan->use == 0.
-hipError_t launch_levels(const uint8_t *render_stack, int S, const uint8_t *warp_stack, int Wn, int npix, LevelPlan *plan,
+hipError_t launch_levels(const uint8_t *render_stack, int S, const uint8_t *warp_stack, int Wn, int npix, int shift, LevelPlan *plan,
                          unsigned long long *post, uint32_t seq, uint32_t max_joint, bool commit, hipStream_t stream);
 hipError_t launch_fewlevels(const GridArgs &a, uint8_t *rank_renders, uint8_t *rank_warps, int workgroups, bool use_bg,
                             hipStream_t stream);

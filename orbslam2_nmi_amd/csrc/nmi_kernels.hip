@@ -681,11 +681,14 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void NMI_GRID_KERNEL_NAME(GridAr
 // The fallback launch behind launch_fewlevels: 256 bins, default histogram variant.
 hipError_t launch_grid_gated(const GridArgs &a, int workgroups, bool use_bg, hipStream_t stream)
 {
-    if (a.shift != 0 || a.hist_variant != 3 || !a.plan) return hipErrorInvalidValue;
-    if (use_bg)
-        hipLaunchKernelGGL((nmi_grid_kernel_gated<true, false, 3>), dim3(workgroups), dim3(kBlock), 0, stream, a);
+    if (a.hist_variant != 3 || !a.plan || (a.shift != 0 && !use_bg)) return hipErrorInvalidValue;
+    const dim3 grid(workgroups), block(kBlock);
+    if (a.shift != 0)
+        hipLaunchKernelGGL((nmi_grid_kernel_gated<true, true, 3>), grid, block, 0, stream, a);
+    else if (use_bg)
+        hipLaunchKernelGGL((nmi_grid_kernel_gated<true, false, 3>), grid, block, 0, stream, a);
     else
-        hipLaunchKernelGGL((nmi_grid_kernel_gated<false, false, 3>), dim3(workgroups), dim3(kBlock), 0, stream, a);
+        hipLaunchKernelGGL((nmi_grid_kernel_gated<false, false, 3>), grid, block, 0, stream, a);
     return hipGetLastError();
 }
 #else  // everything below belongs to the primary translation unit only

@@ -83,6 +83,30 @@ def test_switches(nmi, use_bg, bottom_up, mode):
     check(nmi, rs, ws, w, h, 1, True, bottom_up=bottom_up, use_bg=use_bg, mode=mode)
 
 
+@pytest.mark.parametrize("bins", [128, 64, 32, 16])
+def test_reduced_bin_counts_take_the_path_on_ordinary_content(nmi, bins):
+    """Fewer than 256 bins (intensity >> shift): textured content has at most `bins` levels per stack, so 64 bins and
+    fewer qualify (64 x 64 = 4096 joint bins); 128 bins fall back on the device.  The background rule must be on for
+    shifted bins (with it off, bin 0 mixes skipped and kept intensities): off stays with the general kernel."""
+    from oracle import binding as oc
+    from orbslam2_nmi_amd import synthetic as sy
+    w, h = 320, 240
+    wl = sy.workload(w, h, 9, 9, seed=6)
+    rs, ws = wl["render_stack"], wl["warp_stack"]
+    shift = {128: 1, 64: 2, 32: 3, 16: 4}[bins]
+    for use_bg in (True, False):
+        with nmi.NmiContext(w, h, bins=bins, use_bg=use_bg) as ctx:
+            ctx.set_option(ctx.OPT_CONTENT_PATH, 1)
+            ratings = torch.zeros((9, 9), dtype=torch.float32, device="cuda")
+            idx, best = ctx.search_grid(dev(rs), dev(ws), ratings)
+            info = ctx.last_content()
+        with oc.rounded():
+            ro, io, bo = oc.search_grid(rs, ws, shift=shift, use_bg=use_bg, threads=16)
+        assert (ratings.cpu().numpy().view(np.uint32) == ro.view(np.uint32)).all()
+        assert (idx, best) == (io, bo)
+        assert info["few_levels"] == (use_bg and bins <= 64), (bins, use_bg, info)
+
+
 def test_ordinary_content_falls_back_on_the_device(nmi):
     """Forced few-levels path on textured content: the probe says no, the gated general kernel scores the search."""
     from orbslam2_nmi_amd import synthetic as sy
