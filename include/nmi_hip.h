@@ -318,7 +318,7 @@ int nmi_last_kernel_ms(nmi_ctx *ctx, float *h_ms);
                                   range, merged per row part: nmi_eval_pair = 8 x 4 = 32 workgroups; 4 with 8 row parts only).
                                   -1 (default): see NMI_OPT_SPLIT; 1: never; 2 / 4: that many when it exists and fits. */
 #define NMI_OPT_CONTENT_PATH 12 /* frames with few distinct intensities (posterised, thresholded, quantised): -1 (default)
-                                  automatic -- every 32nd search is probed for the number of distinct intensities in its two
+                                  automatic -- every 32nd search (every 256th once the answer has been the same for a while) is probed for the number of distinct intensities in its two
                                   stacks (nr, nw), and while nr * nw <= NMI_OPT_FEWLEVELS_BINS searches go down the few-levels
                                   path (rank images + 32-bit replicated counters; csrc/nmi_fewlevels_kernel.hip; with fewer than
                                   256 bins the count is of bins, and the background rule must be on); 0: never;

@@ -264,10 +264,20 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
         if ((uint32_t)(posted >> 32) != ctx->level_seen) {
             ctx->level_seen = (uint32_t)(posted >> 32);
             const uint32_t joint = (uint32_t)((posted >> 16) & 0xFFFFu) * (uint32_t)(posted & 0xFFFFu);
-            ctx->few_hint = joint > 0 && joint <= (uint32_t)ctx->fewlevels_bins;
+            const bool hint = joint > 0 && joint <= (uint32_t)ctx->fewlevels_bins;
+            if (hint != ctx->few_hint)
+                ctx->probe_interval = nmi_ctx::kProbeEvery;
+            else if (!hint && ctx->probe_interval < nmi_ctx::kProbeEveryMax)
+                ctx->probe_interval *= 2;  // confirmed once more: look less often
+            ctx->few_hint = hint;
         }
         few = ctx->content_path == 1 || ctx->few_hint;
-        probe_only = !few && (ctx->probe_clock++ % nmi_ctx::kProbeEvery) == 0;
+        if (!few) {
+            probe_only = ctx->probe_wait == 0;
+            ctx->probe_wait = probe_only ? ctx->probe_interval - 1 : ctx->probe_wait - 1;
+        } else {
+            ctx->probe_wait = 0;  // back on ordinary content the first search is probed (it carries its own probe anyway)
+        }
     }
     if (few) {
         const size_t need = (size_t)(S_local + Wn) * (size_t)ctx->npix;
@@ -646,7 +656,8 @@ int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value)
         if (value < -1 || value > 1) return NMI_ERR_INVALID_ARGUMENT;
         ctx->content_path = (int)value;
         ctx->few_hint = false;
-        ctx->probe_clock = 0;
+        ctx->probe_wait = 0;
+        ctx->probe_interval = nmi_ctx::kProbeEvery;
         return NMI_OK;
     case NMI_OPT_FEWLEVELS_BINS:
         if (value < 1 || value > nmi::fewlevels_max_joint()) return NMI_ERR_INVALID_ARGUMENT;

@@ -53,7 +53,7 @@ for name, (rs_h, ws_h) in cases.items():
     rs, ws = torch.from_numpy(np.ascontiguousarray(rs_h)).cuda(), torch.from_numpy(np.ascontiguousarray(ws_h)).cuda()
     ratings = torch.empty((Wn, S), dtype=torch.float32, device="cuda")
     t = []
-    for i in range(48):  # default options: the path follows the content within 32 searches (NMI_OPT_CONTENT_PATH -1)
+    for i in range(300):  # default options: the path follows the content within 32 ... 256 searches (NMI_OPT_CONTENT_PATH -1)
         r = ctx.search_grid(rs, ws, ratings=ratings)
         t.append(ctx.last_kernel_ms() * 1e3)
     us, first = float(np.median(t[-10:])), float(t[0])
