@@ -355,34 +355,83 @@ __device__ __forceinline__ void block_frustum_cull(const float *m_all, int views
 }
 
 // One lane per point, looping over the S views: the cloud is read once, not once per view (27 views of a 3 M-point
-// cloud would otherwise stream 1.3 GB per level); the S matrices sit in LDS.
+// cloud would otherwise stream 1.3 GB per level).
+//
+// Culling is per WAVEFRONT (64 points that are neighbours in the map's own order) and costs no LDS and no barrier, so
+// wavefronts do not wait for each other: the box of the 64 points (DPP / permute reductions), then lane v tests view v --
+// for each of the six clip planes the box corner farthest along the plane's normal, with a margin that covers the
+// rounding of this test and of the per-point test below; a view with that corner outside one plane cannot receive
+// anything from these points.  The clip tests are affine in the position, so the test is exact-conservative: results do
+// not change.  The surviving views come back as one 64-bit ballot; the loop over them is scalar (s_ff1), so each view's
+// matrix arrives through scalar loads instead of 16 LDS reads per view and wavefront.  (The first version culled per
+// 256-point block through LDS with two barriers and kept the matrices in LDS: 73 us for 3 M points x 27 views; this one
+// 62 us = 15 us loading the cloud + 16 us culling + 32 us in the view loop, the atomics being 5 of those -- ablations
+// in DESIGN.md section 7b.)
 constexpr int kMaxViewsPerLaunch = 64;
+
+template <typename T>
+__device__ __forceinline__ T wave_min(T v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
 
 __global__ __launch_bounds__(256) void nmi_splat_kernel(const float *__restrict__ xyz, const float *__restrict__ red, long long npoints,
                                                         const float *__restrict__ mvps, int views, uint32_t *__restrict__ zbuf,
                                                         int width, int height, int size, int stride)
 {
-    __shared__ float m_all[kMaxViewsPerLaunch * 16];
-    __shared__ float wave_box[4][6];
-    __shared__ uint32_t beyond[kMaxViewsPerLaunch];
-    for (int t = threadIdx.x; t < views * 16; t += blockDim.x) m_all[t] = mvps[t];  // column-major like glm: m[c*4 + r]
-    for (int t = threadIdx.x; t < views; t += blockDim.x) beyond[t] = 0x3Fu;
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     const bool valid = i < npoints;
     float x = 0.0f, y = 0.0f, z = 0.0f, r = 0.0f;
     if (valid) x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2], r = red[i];
 
+    // ---- which views can these 64 points reach? ----
+    const float inf = __builtin_huge_valf();
+    const float lox = wave_min(valid ? x : inf), loy = wave_min(valid ? y : inf), loz = wave_min(valid ? z : inf);
+    const float hix = wave_max(valid ? x : -inf), hiy = wave_max(valid ? y : -inf), hiz = wave_max(valid ? z : -inf);
+    const float ax = fmaxf(fabsf(lox), fabsf(hix)), ay = fmaxf(fabsf(loy), fabsf(hiy)), az = fmaxf(fabsf(loz), fabsf(hiz));
+    const int v = (int)(threadIdx.x & 63);
+    bool outside = v >= views;
     {
-        const float inf = __builtin_huge_valf();
-        const float lo[3] = {valid ? x : inf, valid ? y : inf, valid ? z : inf};
-        const float hi[3] = {valid ? x : -inf, valid ? y : -inf, valid ? z : -inf};
-        block_frustum_cull(m_all, views, lo, hi, wave_box, beyond);
+        const float4 *mv = reinterpret_cast<const float4 *>(mvps + (size_t)(v < views ? v : 0) * 16);  // column-major like glm: m[c*4 + r]
+        const float4 c0 = mv[0], c1 = mv[1], c2 = mv[2], c3 = mv[3];
+        const float row[4][4] = {{c0.x, c1.x, c2.x, c3.x}, {c0.y, c1.y, c2.y, c3.y}, {c0.z, c1.z, c2.z, c3.z}, {c0.w, c1.w, c2.w, c3.w}};
+        // magnitude of the terms of cw anywhere in the box (rounding of a 4-term fp32 sum is below 3e-7 of it; margin 1e-5)
+        const float mw = fabsf(row[3][0]) * ax + fabsf(row[3][1]) * ay + fabsf(row[3][2]) * az + fabsf(row[3][3]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float e = 1e-5f * (fabsf(row[j][0]) * ax + fabsf(row[j][1]) * ay + fabsf(row[j][2]) * az + fabsf(row[j][3]) + mw);
+#pragma unroll
+            for (int sgn = 0; sgn < 2; ++sgn) {
+                // plane  cw + c_j >= 0  (sgn 0: c_j >= -cw)   or   cw - c_j >= 0  (sgn 1: c_j <= cw)
+                const float a = sgn ? row[3][0] - row[j][0] : row[3][0] + row[j][0];
+                const float b = sgn ? row[3][1] - row[j][1] : row[3][1] + row[j][1];
+                const float c = sgn ? row[3][2] - row[j][2] : row[3][2] + row[j][2];
+                const float d = sgn ? row[3][3] - row[j][3] : row[3][3] + row[j][3];
+                // the largest value the plane function takes in the box (comparisons with NaN / inf operands are false)
+                const float best = (a * (a >= 0.0f ? hix : lox) + b * (b >= 0.0f ? hiy : loy)) + (c * (c >= 0.0f ? hiz : loz) + d);
+                // the coefficients themselves carry one rounding each: covered by the same margin (twice)
+                outside = outside || best < -2.0f * e;
+            }
+        }
     }
-    if (!valid) return;
+    unsigned long long todo = ~__ballot(outside);
+    if (views < 64) todo &= (1ull << views) - 1ull;
+
     const uint32_t colour = (uint32_t)(fminf(fmaxf(r, 0.0f), 1.0f) * 255.0f + 0.5f);
-    for (int s = 0; s < views; ++s) {
-        if (beyond[s]) continue;  // block-uniform: no point of this block can be inside view s
-        const float *m = m_all + s * 16;
+    while (todo) {  // wavefront-uniform
+        const int s = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        if (!valid) continue;
+        const float *m = mvps + (size_t)s * 16;  // uniform address: scalar loads
         // glm mat4 * vec4: (m0*x + m1*y) + (m2*z + m3*1), component-wise
         const float cx = (m[0] * x + m[4] * y) + (m[8] * z + m[12]);
         const float cy = (m[1] * x + m[5] * y) + (m[9] * z + m[13]);
@@ -407,9 +456,9 @@ __global__ __launch_bounds__(256) void nmi_splat_kernel(const float *__restrict_
         // pixel anyway; the resolve pass below takes, for each pixel, the minimum over the size^2 anchors whose
         // sprites cover it -- exactly the depth-tested sprites.  The buffer is padded by size-1 so that sprites
         // straddling the left / bottom edge keep their anchor.
-        const int ax = x0 + size - 1, ay = y0 + size - 1, wp = width + size - 1, hp = height + size - 1;
-        if (ax < 0 || ax >= wp || ay < 0 || ay >= hp) continue;
-        atomicMin(&zbuf[((size_t)s * hp + ay) * stride + ax], frag);
+        const int ax_ = x0 + size - 1, ay_ = y0 + size - 1, wp = width + size - 1, hp = height + size - 1;
+        if (ax_ < 0 || ax_ >= wp || ay_ < 0 || ay_ >= hp) continue;
+        atomicMin(&zbuf[((size_t)s * hp + ay_) * stride + ax_], frag);
     }
 }
 
