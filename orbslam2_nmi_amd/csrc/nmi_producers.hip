@@ -384,25 +384,74 @@ __device__ __forceinline__ T wave_max(T v)
     return v;
 }
 
+
+__device__ __forceinline__ void splat_point(const float *__restrict__ m, float x, float y, float z, uint32_t colour, uint32_t *__restrict__ zbuf,
+                                            int s, int width, int height, int size, int stride)
+{
+    // glm mat4 * vec4: (m0*x + m1*y) + (m2*z + m3*1), component-wise
+    const float cx = (m[0] * x + m[4] * y) + (m[8] * z + m[12]);
+    const float cy = (m[1] * x + m[5] * y) + (m[9] * z + m[13]);
+    const float cz = (m[2] * x + m[6] * y) + (m[10] * z + m[14]);
+    const float cw = (m[3] * x + m[7] * y) + (m[11] * z + m[15]);
+    if (!(cw > 0.0f) || cx < -cw || cx > cw || cy < -cw || cy > cw || cz < -cw || cz > cw) return;  // point clipping
+    const float xw = (cx / cw * 0.5f + 0.5f) * (float)width;
+    const float yw = (cy / cw * 0.5f + 0.5f) * (float)height;
+    const float zw = cz / cw * 0.5f + 0.5f;
+    const uint32_t depth = (uint32_t)(zw * 16777215.0f + 0.5f);
+    const uint32_t frag = (depth << 8) | colour;
+    int x0, y0;
+    if (size & 1) {
+        x0 = (int)floorf(xw) - (size - 1) / 2;
+        y0 = (int)floorf(yw) - (size - 1) / 2;
+    } else {
+        x0 = (int)floorf(xw + 0.5f) - size / 2;
+        y0 = (int)floorf(yw + 0.5f) - size / 2;
+    }
+    // Only the sprite's anchor (its lowest-left pixel) is written here: one atomic per point and view instead of
+    // size^2.  Two points with the same anchor have the same footprint, so the farther one would lose on every
+    // pixel anyway; the resolve pass below takes, for each pixel, the minimum over the size^2 anchors whose
+    // sprites cover it -- exactly the depth-tested sprites.  The buffer is padded by size-1 so that sprites
+    // straddling the left / bottom edge keep their anchor.
+    const int ax = x0 + size - 1, ay = y0 + size - 1, wp = width + size - 1, hp = height + size - 1;
+    if (ax < 0 || ax >= wp || ay < 0 || ay >= hp) return;
+    atomicMin(&zbuf[((size_t)s * hp + ay) * stride + ax], frag);
+}
+
+// P = points per lane.  Two (a wavefront takes 128 consecutive points: half the culling per point, two loads in flight)
+// measured slower than one: 107 vs 93 us for clear + splat + resolve of 3 M points x 27 views.
+template <int P>
 __global__ __launch_bounds__(256) void nmi_splat_kernel(const float *__restrict__ xyz, const float *__restrict__ red, long long npoints,
                                                         const float *__restrict__ mvps, int views, uint32_t *__restrict__ zbuf,
                                                         int width, int height, int size, int stride)
 {
-    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    const bool valid = i < npoints;
-    float x = 0.0f, y = 0.0f, z = 0.0f, r = 0.0f;
-    if (valid) x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2], r = red[i];
+    const int lane = (int)(threadIdx.x & 63);
+    // lane v's view matrix for the culling test below: asked for first, it is needed last
+    const float4 *mv = reinterpret_cast<const float4 *>(mvps + (size_t)(lane < views ? lane : 0) * 16);  // column-major like glm: m[c*4 + r]
+    const float4 c0 = mv[0], c1 = mv[1], c2 = mv[2], c3 = mv[3];
+    const long long wave = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+    bool valid[P];
+    float x[P], y[P], z[P], r[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        const long long i = (wave * P + q) * 64 + lane;
+        valid[q] = i < npoints;
+        x[q] = y[q] = z[q] = r[q] = 0.0f;
+        if (valid[q]) x[q] = xyz[3 * i], y[q] = xyz[3 * i + 1], z[q] = xyz[3 * i + 2], r[q] = red[i];
+    }
 
-    // ---- which views can these 64 points reach? ----
+    // ---- which views can these points reach? ----
     const float inf = __builtin_huge_valf();
-    const float lox = wave_min(valid ? x : inf), loy = wave_min(valid ? y : inf), loz = wave_min(valid ? z : inf);
-    const float hix = wave_max(valid ? x : -inf), hiy = wave_max(valid ? y : -inf), hiz = wave_max(valid ? z : -inf);
+    float lx = inf, ly = inf, lz = inf, hx = -inf, hy = -inf, hz = -inf;
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        lx = fminf(lx, valid[q] ? x[q] : inf), ly = fminf(ly, valid[q] ? y[q] : inf), lz = fminf(lz, valid[q] ? z[q] : inf);
+        hx = fmaxf(hx, valid[q] ? x[q] : -inf), hy = fmaxf(hy, valid[q] ? y[q] : -inf), hz = fmaxf(hz, valid[q] ? z[q] : -inf);
+    }
+    const float lox = wave_min(lx), loy = wave_min(ly), loz = wave_min(lz);
+    const float hix = wave_max(hx), hiy = wave_max(hy), hiz = wave_max(hz);
     const float ax = fmaxf(fabsf(lox), fabsf(hix)), ay = fmaxf(fabsf(loy), fabsf(hiy)), az = fmaxf(fabsf(loz), fabsf(hiz));
-    const int v = (int)(threadIdx.x & 63);
-    bool outside = v >= views;
+    bool outside = lane >= views;
     {
-        const float4 *mv = reinterpret_cast<const float4 *>(mvps + (size_t)(v < views ? v : 0) * 16);  // column-major like glm: m[c*4 + r]
-        const float4 c0 = mv[0], c1 = mv[1], c2 = mv[2], c3 = mv[3];
         const float row[4][4] = {{c0.x, c1.x, c2.x, c3.x}, {c0.y, c1.y, c2.y, c3.y}, {c0.z, c1.z, c2.z, c3.z}, {c0.w, c1.w, c2.w, c3.w}};
         // magnitude of the terms of cw anywhere in the box (rounding of a 4-term fp32 sum is below 3e-7 of it; margin 1e-5)
         const float mw = fabsf(row[3][0]) * ax + fabsf(row[3][1]) * ay + fabsf(row[3][2]) * az + fabsf(row[3][3]);
@@ -426,39 +475,16 @@ __global__ __launch_bounds__(256) void nmi_splat_kernel(const float *__restrict_
     unsigned long long todo = ~__ballot(outside);
     if (views < 64) todo &= (1ull << views) - 1ull;
 
-    const uint32_t colour = (uint32_t)(fminf(fmaxf(r, 0.0f), 1.0f) * 255.0f + 0.5f);
+    uint32_t colour[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) colour[q] = (uint32_t)(fminf(fmaxf(r[q], 0.0f), 1.0f) * 255.0f + 0.5f);
     while (todo) {  // wavefront-uniform
         const int s = __builtin_ctzll(todo);
         todo &= todo - 1ull;
-        if (!valid) continue;
         const float *m = mvps + (size_t)s * 16;  // uniform address: scalar loads
-        // glm mat4 * vec4: (m0*x + m1*y) + (m2*z + m3*1), component-wise
-        const float cx = (m[0] * x + m[4] * y) + (m[8] * z + m[12]);
-        const float cy = (m[1] * x + m[5] * y) + (m[9] * z + m[13]);
-        const float cz = (m[2] * x + m[6] * y) + (m[10] * z + m[14]);
-        const float cw = (m[3] * x + m[7] * y) + (m[11] * z + m[15]);
-        if (!(cw > 0.0f) || cx < -cw || cx > cw || cy < -cw || cy > cw || cz < -cw || cz > cw) continue;  // point clipping
-        const float xw = (cx / cw * 0.5f + 0.5f) * (float)width;
-        const float yw = (cy / cw * 0.5f + 0.5f) * (float)height;
-        const float zw = cz / cw * 0.5f + 0.5f;
-        const uint32_t depth = (uint32_t)(zw * 16777215.0f + 0.5f);
-        const uint32_t frag = (depth << 8) | colour;
-        int x0, y0;
-        if (size & 1) {
-            x0 = (int)floorf(xw) - (size - 1) / 2;
-            y0 = (int)floorf(yw) - (size - 1) / 2;
-        } else {
-            x0 = (int)floorf(xw + 0.5f) - size / 2;
-            y0 = (int)floorf(yw + 0.5f) - size / 2;
-        }
-        // Only the sprite's anchor (its lowest-left pixel) is written here: one atomic per point and view instead of
-        // size^2.  Two points with the same anchor have the same footprint, so the farther one would lose on every
-        // pixel anyway; the resolve pass below takes, for each pixel, the minimum over the size^2 anchors whose
-        // sprites cover it -- exactly the depth-tested sprites.  The buffer is padded by size-1 so that sprites
-        // straddling the left / bottom edge keep their anchor.
-        const int ax_ = x0 + size - 1, ay_ = y0 + size - 1, wp = width + size - 1, hp = height + size - 1;
-        if (ax_ < 0 || ax_ >= wp || ay_ < 0 || ay_ >= hp) continue;
-        atomicMin(&zbuf[((size_t)s * hp + ay_) * stride + ax_], frag);
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+            if (valid[q]) splat_point(m, x[q], y[q], z[q], colour[q], zbuf, s, width, height, size, stride);
     }
 }
 
@@ -1006,7 +1032,7 @@ hipError_t launch_render_points(const float *xyz, const float *red, long long np
         const size_t per_view = (size_t)stride * (height + size - 1);
         for (int s0 = 0; s0 < S; s0 += kMaxViewsPerLaunch) {
             const int views = S - s0 < kMaxViewsPerLaunch ? S - s0 : kMaxViewsPerLaunch;
-            hipLaunchKernelGGL(nmi_splat_kernel, dim3((unsigned)((npoints + 255) / 256)), dim3(256), 0, stream, xyz, red, npoints,
+            hipLaunchKernelGGL(nmi_splat_kernel<1>, dim3((unsigned)((npoints + 255) / 256)), dim3(256), 0, stream, xyz, red, npoints,
                                mvps + (size_t)s0 * 16, views, zbuf + (size_t)s0 * per_view, width, height, size, stride);
         }
     }
