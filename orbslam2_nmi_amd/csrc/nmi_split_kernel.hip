@@ -505,21 +505,42 @@ __device__ __forceinline__ bool merge_pixel_parts(SplitLds<K> &lds, const GridAr
     return true;
 }
 
+// Kernel arguments are read afresh in every phase (fresh(): the pointer to the kernel-argument segment goes through an
+// empty asm so that the loads of one phase cannot be merged with those of another).  By-value arguments are otherwise
+// loaded once and kept in scalar registers for the whole kernel; this kernel then spilled 60 of them to VGPR lanes, and
+// two of their stack slots survived in the kernel descriptor as 36 bytes of private segment that no instruction touches.
+// Now: no spills, no private segment.  (What a launch pays for merely asking for scratch is small -- 0.5-0.7 us of the
+// 8.2 us a blocking launch of 32 empty workgroups takes, tools/ubench/launch_latency.hip; an nmi_eval_pair call went
+// from 21.0 to 20.1-20.3 us.)
 template <int K, int P, bool FAST>
-__global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_split_kernel(GridArgs a, int use_bg)
+__global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_split_kernel(GridArgs a_by_value, int use_bg)
 {
     __shared__ SplitLds<K> lds;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    typedef const GridArgs __attribute__((address_space(4))) *kernargs_t;
+    auto fresh = [&]() {
+        kernargs_t ka = (kernargs_t)__builtin_amdgcn_kernarg_segment_ptr();  // GridArgs is the first argument
+        asm volatile("" : "+s"(ka));
+        return *(const GridArgs *)ka;  // (the compiler sees through the cast: scalar loads from the constant address space)
+    };
+    (void)a_by_value;
 
     auto stamp = [&](int k) {  // tools/small_grid_time.py --stamps: where a part's time goes (100 MHz clock)
+        const GridArgs a = fresh();
         if (a.dbg_stamps && tid == 0) a.dbg_stamps[blockIdx.x * 8 + k] = wall_clock64();
     };
     stamp(0);
-    const long long clk0 = a.dbg_stamps ? clock64() : 0;  // shader-clock counter: with the wall-clock stamps it gives the clock held
-    if (blockIdx.x == 0 && tid == 0 && a.reset_key) *a.reset_key = 0ull;  // next launch's slot; idle during this one
-    const int total = a.S_local * a.Wn;
+    long long clk0 = 0;
+    int total, phase_mask;
+    {
+        const GridArgs a = fresh();
+        clk0 = a.dbg_stamps ? clock64() : 0;  // shader-clock counter: with the wall-clock stamps it gives the clock held
+        if (blockIdx.x == 0 && tid == 0 && a.reset_key) *a.reset_key = 0ull;  // next launch's slot; idle during this one
+        total = a.S_local * a.Wn;
+        phase_mask = a.phase_mask;
+    }
     {
         uint4 *j4 = reinterpret_cast<uint4 *>(lds.joint);
         const uint4 z = {0, 0, 0, 0};
@@ -536,36 +557,55 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_split_kernel(GridArgs a
         int p, part, pix_part;
         split_unit(u, total, K, P, p, part, pix_part);
         if (p >= total) continue;  // workgroup-uniform
-        const int w = p / a.S_local, s = p - w * a.S_local;
-        SplitSlab *slab = a.slabs + p;
 
         stamp(1);
-        if (a.phase_mask & 1)
+        if (phase_mask & 1) {
+            const GridArgs a = fresh();
+            const int w = p / a.S_local, s = p - w * a.S_local;
             histogram_split<K, FAST>(lds.joint, a, a.pair_renders ? a.pair_renders[p] : a.render_stack + (size_t)s * a.npix,
                                      a.pair_warps ? a.pair_warps[p] : a.warp_stack + (size_t)w * a.npix, tid, part, use_bg != 0, pix_part, P);
+        }
         __syncthreads();
         stamp(2);
-        if (P > 1 && !merge_pixel_parts<K, P>(lds, a, p, part, pix_part, tid)) continue;  // workgroup-uniform
-        decode_split<K>(lds, a, slab, part, wave, lane);
+        if (P > 1) {
+            const GridArgs a = fresh();
+            if (!merge_pixel_parts<K, P>(lds, a, p, part, pix_part, tid)) continue;  // workgroup-uniform
+        }
+        {
+            const GridArgs a = fresh();
+            decode_split<K>(lds, a, a.slabs + p, part, wave, lane);
+        }
         __syncthreads();
         stamp(3);
-        if (tid < kBins) {
-            // (phase mask bit 9, tests only: part 1 keeps its column sums to itself, so the scorer's wait must time out)
-            if (!((a.phase_mask & 512) && part == 1)) store_granule(&slab->hw_part[part][tid], granule32(lds.hist_warped[tid], a.epoch));
-            lds.hist_warped[tid] = 0;
+        {
+            const GridArgs a = fresh();
+            SplitSlab *slab = a.slabs + p;
+            if (tid < kBins) {
+                // (phase mask bit 9, tests only: part 1 keeps its column sums to itself, so the scorer's wait must time out)
+                if (!((phase_mask & 512) && part == 1)) store_granule(&slab->hw_part[part][tid], granule32(lds.hist_warped[tid], a.epoch));
+                lds.hist_warped[tid] = 0;
+            }
+            if (part != 0) continue;  // workgroup-uniform: only part 0 scores the candidate
+            gather_slab<K>(lds, a, slab, tid);
         }
-        if (part != 0) continue;  // workgroup-uniform: only part 0 scores the candidate
-        gather_slab<K>(lds, a, slab, tid);
         __syncthreads();
         stamp(4);
         if (wave == 0) {
+            const GridArgs a = fresh();
+            const int w = p / a.S_local, s = p - w * a.S_local;
             final_split<K>(lds, a, lane, p, w, s, prev_key);
             stamp(5);
         }
     }
-    if (tid == 0 && !(a.phase_mask & 16)) publish_winner(a, prev_key);
+    if (tid == 0 && !(phase_mask & 16)) {
+        const GridArgs a = fresh();
+        publish_winner(a, prev_key);
+    }
     stamp(6);
-    if (a.dbg_stamps && tid == 0) a.dbg_stamps[blockIdx.x * 8 + 7] = (unsigned long long)(clock64() - clk0);
+    {
+        const GridArgs a = fresh();
+        if (a.dbg_stamps && tid == 0) a.dbg_stamps[blockIdx.x * 8 + 7] = (unsigned long long)(clock64() - clk0);
+    }
 }
 
 __host__ __device__ int split_workgroups(int candidates, int parts, int pix_parts)
