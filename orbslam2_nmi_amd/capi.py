@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = (
     "nmi_texture_destroy", "nmi_render_mesh", "nmi_stream_create", "nmi_stream_destroy",
     "nmi_stream_submit", "nmi_stream_wait", "nmi_stream_keep_ratings", "nmi_stream_copy_ratings", "nmi_key_pack", "nmi_key_unpack", "nmi_search_grid_rccl", "nmi_search_grid_block_rccl",
     "nmi_rccl_unique_id", "nmi_rccl_comm_init", "nmi_rccl_comm_destroy", "nmi_set_profiling", "nmi_last_kernel_ms",
-    "nmi_set_option", "nmi_copy_term_table", "nmi_abi_version", "nmi_error_string", "nmi_last_error_detail", "nmi_get_info", "nmi_last_content",
+    "nmi_set_option", "nmi_copy_term_table", "nmi_abi_version", "nmi_error_string", "nmi_last_error_detail", "nmi_get_info", "nmi_last_content", "nmi_sort_points", "nmi_sort_triangles",
 )
 
 
@@ -117,6 +117,8 @@ def load_library(build_if_missing=False):
     lib.nmi_last_error_detail.restype = C.c_char_p
     lib.nmi_get_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     lib.nmi_last_content.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    lib.nmi_sort_points.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
+    lib.nmi_sort_triangles.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
     _lib = lib
     return lib
 
@@ -323,6 +325,30 @@ class NmiContext:
                                                   h1.data_ptr(), h2.data_ptr(), sums.data_ptr()), "nmi_eval_pair_debug")
         u32 = lambda t: t.cpu().numpy().view(np.uint32)
         return np.float32(out.value), u32(joint).reshape(256, 256), u32(h1), u32(h2), sums.cpu().numpy()
+
+    def sort_points(self, xyz, red):
+        """Point cloud (device float32 [N,3], [N]) -> copies in Morton order (nmi_sort_points): same renders, faster."""
+        import torch
+        assert xyz.is_cuda and red.is_cuda and xyz.dtype == torch.float32 and red.dtype == torch.float32
+        xyz, red = xyz.contiguous(), red.contiguous()
+        n = xyz.shape[0]
+        assert tuple(xyz.shape) == (n, 3) and red.numel() == n
+        xo, ro = torch.empty_like(xyz), torch.empty_like(red)
+        self._order_after_torch()
+        self._check(self._lib.nmi_sort_points(self._h, xyz.data_ptr(), red.data_ptr(), n, xo.data_ptr(), ro.data_ptr()), "nmi_sort_points")
+        return xo, ro
+
+    def sort_triangles(self, xyz, uv):
+        """Triangle soup (device float32 [3T,3] corners, [3T,2] texture coordinates) -> copies in Morton order of the centroids."""
+        import torch
+        assert xyz.is_cuda and uv.is_cuda and xyz.dtype == torch.float32 and uv.dtype == torch.float32
+        xyz, uv = xyz.contiguous(), uv.contiguous()
+        t = xyz.shape[0] // 3
+        assert tuple(xyz.shape) == (3 * t, 3) and tuple(uv.shape) == (3 * t, 2)
+        xo, uo = torch.empty_like(xyz), torch.empty_like(uv)
+        self._order_after_torch()
+        self._check(self._lib.nmi_sort_triangles(self._h, xyz.data_ptr(), uv.data_ptr(), t, xo.data_ptr(), uo.data_ptr()), "nmi_sort_triangles")
+        return xo, uo
 
     def warp_stack(self, frame, homographies, out=None, sync=True):
         """Image::calculateWarping (image.cpp:115-128) on the device: frame [H,W] u8 + forward homographies [Wn,3,3]

@@ -266,4 +266,24 @@ int nmi_render_mesh(nmi_ctx *ctx, const float *d_xyz, const float *d_uv, int64_t
     return NMI_OK;
 }
 
+int nmi_sort_points(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int64_t n_points, float *d_xyz_out, float *d_red_out)
+{
+    if (!ctx || n_points < 0 || n_points >= (1ll << 32)) return NMI_ERR_INVALID_ARGUMENT;
+    if (n_points > 0 && (!d_xyz || !d_red || !d_xyz_out || !d_red_out || d_xyz == d_xyz_out || d_red == d_red_out)) return NMI_ERR_INVALID_ARGUMENT;
+    ctx->detail.clear();
+    DeviceGuard guard(ctx->device);
+    NMI_HIP_TRY(ctx, nmi::sort_records_morton(d_xyz, 3, 1, d_red, 1, n_points, d_xyz_out, d_red_out, ctx->stream));
+    return NMI_OK;
+}
+
+int nmi_sort_triangles(nmi_ctx *ctx, const float *d_xyz, const float *d_uv, int64_t n_triangles, float *d_xyz_out, float *d_uv_out)
+{
+    if (!ctx || n_triangles < 0 || n_triangles >= (1ll << 32)) return NMI_ERR_INVALID_ARGUMENT;
+    if (n_triangles > 0 && (!d_xyz || !d_uv || !d_xyz_out || !d_uv_out || d_xyz == d_xyz_out || d_uv == d_uv_out)) return NMI_ERR_INVALID_ARGUMENT;
+    ctx->detail.clear();
+    DeviceGuard guard(ctx->device);
+    NMI_HIP_TRY(ctx, nmi::sort_records_morton(d_xyz, 9, 3, d_uv, 6, n_triangles, d_xyz_out, d_uv_out, ctx->stream));
+    return NMI_OK;
+}
+
 }  // extern "C"

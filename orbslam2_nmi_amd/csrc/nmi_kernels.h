@@ -140,6 +140,10 @@ size_t render_zbuf_words(int S, int width, int height, int size);
 hipError_t launch_render_points(const float *xyz, const float *red, long long npoints, const float *mvps /*[S][16] column-major*/,
                                 int S, uint32_t *zbuf /*[render_zbuf_words]*/, uint8_t *out, int width, int height, int size, hipStream_t stream,
                                 bool clear_first = true);
+// nmi_sort.hip: records (na floats each in `a`, the first 3 * verts being vertices; nb floats each in `b`, may be null) into
+// Morton order of their positions.  Drains the stream.
+hipError_t sort_records_morton(const float *a, int na, int verts, const float *b, int nb, long long n, float *a_out, float *b_out,
+                               hipStream_t stream);
 hipError_t launch_level_prep(const float *h_mvps, float *d_mvps, int n_mvps, const float *h_coeffs, float *d_coeffs, int n_coeffs,
                              unsigned long long *key, uint32_t *zbuf, size_t nz, hipStream_t stream);
 

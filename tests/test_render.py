@@ -422,3 +422,53 @@ def test_gpu_mesh_level_graph_equals_separate_calls():
                 rs = ctx.render_mesh(dx, du, tex, mvps)
                 ws = ctx.warp_stack(frame, Ms)
                 assert got == ctx.search_grid(rs, ws), lvl
+
+
+@pytest.mark.gpu
+def test_gpu_sorted_maps_are_permutations_and_render_identically():
+    """nmi_sort_points / nmi_sort_triangles (Morton order, device radix sort): the output is a permutation of the input
+    records (NaN / inf positions last), neighbours in memory are neighbours in space, and the renders do not change."""
+    torch = pytest.importorskip("torch")
+    import orbslam2_nmi_amd as nmi
+    w, h = 160, 120
+    rng = np.random.default_rng(5)
+    views = np.stack([capi.render_mvp(params(w, h), (0.1 * k, 0, 0), (0.1 * k, 0, 1), (0, -1, 0), (0, 0, 0.2 * k)) for k in range(3)])  # noqa
+    with nmi.NmiContext(w, h) as ctx:
+        # points
+        xyz, red, rp = plane_cloud(w, h, density=3.0)
+        perm = rng.permutation(len(xyz))
+        xyz, red = xyz[perm].copy(), red[perm].copy()
+        xyz[5] = [np.nan, 0, 10]
+        xyz[77] = [0, np.inf, 10]
+        dx, dr = torch.from_numpy(xyz).cuda(), torch.from_numpy(red).cuda()
+        sx, sr = ctx.sort_points(dx, dr)
+        a = np.concatenate([xyz, red[:, None]], 1)
+        b = np.concatenate([sx.cpu().numpy(), sr.cpu().numpy()[:, None]], 1)
+        key = lambda m: m[np.lexsort(np.nan_to_num(m, nan=1e30, posinf=2e30, neginf=-2e30).T[::-1])]
+        assert np.array_equal(key(a), key(b), equal_nan=True)                   # same multiset of records
+        assert not np.isfinite(b[-2:, :3]).all(1).any() and np.isfinite(b[:-2, :3]).all()  # the two bad points went last
+        step_in = np.linalg.norm(np.diff(xyz[np.isfinite(xyz).all(1)], axis=0), axis=1).mean()
+        step_out = np.linalg.norm(np.diff(b[:-2, :3], axis=0), axis=1).mean()
+        assert step_out < 0.1 * step_in                                          # consecutive points are now close
+        r0 = ctx.render_points(dx, dr, views, 3.0).cpu().numpy()
+        r1 = ctx.render_points(sx, sr, views, 3.0).cpu().numpy()
+        assert (r0 == r1).all() and (r0 != 255).mean() > 0.3
+        # triangles
+        txyz, tuv, tex, _ = plane_mesh(w, h)
+        t = len(txyz) // 3
+        tp = rng.permutation(t)
+        txyz = txyz.reshape(t, 9)[tp].reshape(-1, 3).copy()
+        tuv = tuv.reshape(t, 6)[tp].reshape(-1, 2).copy()
+        dtx, dtu = torch.from_numpy(txyz).cuda(), torch.from_numpy(tuv).cuda()
+        stx, stu = ctx.sort_triangles(dtx, dtu)
+        a = np.concatenate([txyz.reshape(t, 9), tuv.reshape(t, 6)], 1)
+        b = np.concatenate([stx.cpu().numpy().reshape(t, 9), stu.cpu().numpy().reshape(t, 6)], 1)
+        assert np.array_equal(key(a), key(b))
+        with nmi.NmiTexture(ctx, tex) as texture:
+            m0 = ctx.render_mesh(dtx, dtu, texture, views).cpu().numpy()
+            m1 = ctx.render_mesh(stx, stu, texture, views).cpu().numpy()
+        assert (m0 == m1).all() and (m0 != 255).mean() > 0.3
+        # empty maps and aliasing are handled
+        e = torch.empty((0, 3), dtype=torch.float32, device="cuda")
+        ex, er = ctx.sort_points(e, torch.empty(0, dtype=torch.float32, device="cuda"))
+        assert ex.shape[0] == 0
