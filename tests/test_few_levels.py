@@ -114,6 +114,11 @@ def test_ordinary_content_falls_back_on_the_device(nmi):
     wl = sy.workload(w, h, 9, 9, seed=4)
     info = check(nmi, wl["render_stack"], wl["warp_stack"], w, h, 1, False)
     assert info["nr"] * info["nw"] > 4096
+    # the same with the background rule off (another instantiation of the gated kernel; zeros planted in both stacks)
+    rs, ws = wl["render_stack"].copy(), wl["warp_stack"].copy()
+    rs[:, 10:40, 50:90] = 0
+    ws[:, 100:130, 200:260] = 0
+    check(nmi, rs, ws, w, h, 1, False, use_bg=False)
     # a lower limit (NMI_OPT_FEWLEVELS_BINS): 33 x 64 levels fall back at 2048, pass at the default 4096
     rs, ws = quantise(wl["render_stack"], 33), quantise(wl["warp_stack"], 64)
     info = check(nmi, rs, ws, w, h, 1, None, bins_limit=2048)
