@@ -13,6 +13,9 @@ python3 tools/small_grid_content.py 2>/dev/null | grep levels= > "$OUT/small_gri
 python3 tools/bg_off_time.py 2>/dev/null | grep use_bg > "$OUT/bg_off_time.txt" || exit 1
 python3 tools/mesh_time.py > "$OUT/mesh_time.txt" 2>/dev/null || exit 1
 ./examples/relocalize_demo 2>&1 | grep -i "evals\|SHIM" > "$OUT/shim_rate.txt" || exit 1
+python3 tools/cloud_order_time.py 2>/dev/null | grep -v amdgpu.ids > "$OUT/cloud_order_time.txt" || exit 1
+[ -x tools/ubench/launch_latency ] || hipcc --offload-arch=gfx950 -O2 -o tools/ubench/launch_latency tools/ubench/launch_latency.hip 2>/dev/null
+./tools/ubench/launch_latency > "$OUT/launch_latency.txt" || exit 1
 ./examples/level_pipeline > "$OUT/level_pipeline.txt" 2>&1 || exit 1
 cd /tmp && export TMPDIR=/tmp
 rm -rf "$OUT/e2e_trace"
