@@ -21,7 +21,7 @@ from oracle import binding as ob
 SHAPES = [(640, 480), (848, 480), (320, 240), (960, 540), (64, 48), (100, 75), (333, 100), (32, 2), (1280, 720)]
 
 
-def run(cases=200, seed=1, verbose=True, options=None, kinds=6):
+def run(cases=200, seed=1, verbose=True, options=None, kinds=6, max_side=8):
     rng = np.random.default_rng(seed)
 
     def content(kind, n, h, w):
@@ -56,7 +56,7 @@ def run(cases=200, seed=1, verbose=True, options=None, kinds=6):
     worst = 0.0
     for c in range(cases):
         w, h = SHAPES[int(rng.integers(len(SHAPES)))]
-        S, Wn = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+        S, Wn = int(rng.integers(1, max_side + 1)), int(rng.integers(1, max_side + 1))
         kr, kw = int(rng.integers(0, kinds)), int(rng.integers(0, kinds))
         rs, ws = content(kr, S, h, w), content(kw, Wn, h, w)
         if rng.random() < 0.3 and kr >= 3:  # the same flat rows in both stacks: flat-over-flat pairs
