@@ -255,7 +255,8 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     // Few-levels path (nmi_fewlevels_kernel.hip).  The decision rests on what the most recent probe of a search's stacks
     // found (frames and renders of consecutive searches look alike); it is only a matter of speed, because the probe that
     // goes with every few-levels launch hands the search back to nmi_grid_kernel (gated launch below) when this
-    // search's stacks do not qualify.  While the hint says "ordinary content", every kProbeEvery-th search is probed.
+    // search's stacks do not qualify.  While the hint says "ordinary content", every kProbeEvery-th search is probed, every
+    // 2 kProbeEvery-th ... kProbeEveryMax-th once probes keep confirming it.
     bool few = false, probe_only = false;
     const bool few_eligible = !parts && a.vec_ok && (ctx->shift == 0 || p.use_bg) && ctx->hist_variant == 3 && ctx->phase_mask == 3 && !dbg_joint &&
                               !dbg_h1 && !dbg_h2 && !dbg_sums && !ctx->pair_renders && !ctx->dbg_stamps && ctx->content_path != 0;
