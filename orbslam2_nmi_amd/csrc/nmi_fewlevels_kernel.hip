@@ -14,6 +14,7 @@
 //                         every lane of an LDS access group owns a bank, so 64 lanes adding to ONE bin cost what 64
 //                         lanes adding to 64 bins cost.  The copies are summed, the counts put back at their intensities
 //                         in 256-wide rows (absent intensities are the zeros the reference would add), then the trees.
+// With fewer than 256 bins (intensity >> shift) read "bin" for "intensity": textured content then qualifies from 64 bins down.
 // All three exit at once when the plan says `use` = 0; the host enqueues nmi_grid_kernel behind them in its gated form,
 // which runs exactly then.  Nothing here waits for another workgroup except through kernel boundaries.
 #include <hip/hip_runtime.h>
