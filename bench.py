@@ -420,10 +420,12 @@ def main():
             wk.wait()
         for st_ in streams[1:]:
             streams[0].wait_stream(st_)
-        got = keys[:n].cpu().tolist()  # one read-back of all winners; synchronises the stream
-        bad = [g for g in got if nmi.key_unpack(g)[0] != planted_global]
-        if bad:
-            sys.exit(f"rank {rank}: {len(bad)} wrong winners, e.g. {nmi.key_unpack(bad[0])} (expected index {planted_global})")
+        got = keys[:n].cpu().numpy().view(np.uint64)  # one read-back of all winners; synchronises the stream
+        # packed key = score bits << 32 | (0xFFFFFFFF - index), 0 = no winner (nmi_key_unpack, vectorised)
+        idx = np.where(got == 0, -1, 0xFFFFFFFF - (got & np.uint64(0xFFFFFFFF)).astype(np.int64))
+        bad = got[idx != planted_global]
+        if bad.size:
+            sys.exit(f"rank {rank}: {bad.size} wrong winners, e.g. {nmi.key_unpack(int(bad[0]))} (expected index {planted_global})")
 
     run = run_blocking if args.blocking else run_async
 
