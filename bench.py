@@ -439,10 +439,14 @@ def main():
     # reach its sustained clock, and a timed region of K = 20 steps is 1.8 ms -- measured cold it reads 8 % low (kernel 86 us
     # instead of 79).  Same searches as the steps; then the W warm-up steps and the K timed steps as the contract says.
     if args.clock_warmup_ms > 0:
+        # a step COUNT fixed by the arguments alone (every rank must issue the same collectives), sized from the
+        # expected step time: 0.08 ms for 729 candidates at 640x480, scaled by candidates x pixels
+        est_ms = 0.08 * (S_PER_RANK * WN * WIDTH * HEIGHT) / (729.0 * 640 * 480)
+        todo = max(1, int(round(args.clock_warmup_ms / est_ms)))
         chunk = max(1, min(n_slots, 100))
-        tw = time.perf_counter()
-        while (time.perf_counter() - tw) * 1e3 < args.clock_warmup_ms:
-            run(chunk)
+        while todo > 0:
+            run(min(chunk, todo))
+            todo -= chunk
     run(args.warmup)
     sync_all()
     t0 = time.perf_counter()
