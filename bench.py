@@ -380,6 +380,7 @@ def main():
     # (every step = one blocking nmi_search_grid call / kernel + collective + read-back before the next launch).
     n_slots = max(args.steps, args.warmup, 1)
     keys = torch.zeros(n_slots, dtype=torch.int64, device="cuda")
+    keys_host = torch.zeros(n_slots, dtype=torch.int64).pin_memory()
 
     def run_blocking(n):
         res = None
@@ -420,7 +421,9 @@ def main():
             wk.wait()
         for st_ in streams[1:]:
             streams[0].wait_stream(st_)
-        got = keys[:n].cpu().numpy().view(np.uint64)  # one read-back of all winners; synchronises the stream
+        keys_host[:n].copy_(keys[:n], non_blocking=True)  # one read-back of all winners into pinned memory ...
+        torch.cuda.current_stream().synchronize()           # ... and the only wait of the region
+        got = keys_host[:n].numpy().view(np.uint64)
         # packed key = score bits << 32 | (0xFFFFFFFF - index), 0 = no winner (nmi_key_unpack, vectorised)
         idx = np.where(got == 0, -1, 0xFFFFFFFF - (got & np.uint64(0xFFFFFFFF)).astype(np.int64))
         bad = got[idx != planted_global]
