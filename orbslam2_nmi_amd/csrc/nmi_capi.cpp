@@ -287,8 +287,10 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
             if (ctx->d_rank_stacks) NMI_HIP_TRY(ctx, hipFree(ctx->d_rank_stacks));
             ctx->d_rank_stacks = nullptr;
             ctx->rank_bytes = 0;
-            NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_rank_stacks, need));
-            ctx->rank_bytes = need;
+            // with headroom: a coarse-to-fine search alternates between grid shapes, and growing drains the stream
+            const size_t want = need + need / 2;
+            NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_rank_stacks, want));
+            ctx->rank_bytes = want;
         }
         a.plan = ctx->d_plan;
     }
