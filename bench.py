@@ -63,6 +63,17 @@ def cpu_baseline(wl, budget_s=12.0, max_threads=16):
             "single_thread": single}
 
 
+def kernel_source_id():
+    """sha256 (first 16 hex digits) of the dominant kernel's sources: the stamp tools/summarize_profiles.py puts on a PMC
+    profile when it is taken, and what bench.py compares it with -- a committed counter profile of another kernel says so."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("nmi_kernels.hip", "nmi_device.h", "nmi_kernels.h"):
+        with open(os.path.join(ROOT, "orbslam2_nmi_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def load_pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed PMC profile (profiles/), or None."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -73,20 +84,108 @@ def load_pmc_traffic():
         return None
 
 
+def static_profile_stamp():
+    """roofline.traffic / roofline.lds are NOT measured by this run (PMC passes need rocprofv3): they come from the committed
+    profiles/pmc_*.json.  This says so, names the profile and whether the kernel sources still are the ones it was taken on."""
+    out = {"static_profile": True, "kernel_source_sha16_now": kernel_source_id()}
+    for key, name in (("traffic", "pmc_traffic.json"), ("lds", "pmc_lds.json")):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            out[key] = {"source": d.get("source"), "kernel_source_sha16": d.get("kernel_source_sha16"),
+                        "stale": d.get("kernel_source_sha16") != out["kernel_source_sha16_now"]}
+        except (OSError, ValueError):
+            out[key] = None
+    return out
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python3 bench.py --gpus N` without a launcher (the way the round-end driver calls it): start the N ranks ourselves as
+    CHILD processes of torch.distributed.run -- before this process has touched the GPU, and never by replacing it (an exec
+    from a process that initialised HIP takes the box down) -- relay their output and return their exit code.
+    torch.cuda.device_count() does not initialise the device on this image."""
+    import subprocess
+
+    import torch
+    visible = torch.cuda.device_count()
+    if not (args.all_on_device0 or args.dry_launch) and visible < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible HIP devices, this host shows {visible} "
+              f"(rehearsal on fewer devices: --backend gloo --all-on-device0)", file=sys.stderr)
+        return 2
+    if args.all_on_device0 and args.backend == "nccl" and args.gpus > 1:
+        print("bench.py: --all-on-device0 needs --backend gloo (RCCL refuses two ranks on one device)", file=sys.stderr)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's intra-node transport needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_launch(args):
+    """--dry-launch: every rank reports the rendezvous it was given and the device it WOULD select, touching no GPU; the
+    ranks meet once over gloo (so the launch, the rendezvous and a collective are exercised on a CPU-only host)."""
+    import torch
+    import torch.distributed as dist
+    rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
+    if world != args.gpus:
+        sys.exit(f"bench.py: WORLD_SIZE {world} does not match --gpus {args.gpus}")
+    mine = {"rank": rank, "local_rank": local_rank, "device": 0 if args.all_on_device0 else local_rank,
+            "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}", "pid": os.getpid()}
+    ranks = [mine]
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert int(t.item()) == world
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "config": args.config, "backend": args.backend,
+                          "devices_visible": torch.cuda.device_count(), "ranks": ranks}))
+    return 0
+
+
+def rank_evidence(world, dist, local_device):
+    """What a reader needs to see that the collective really spanned N ranks: the size of the process group as the backend
+    reports it, the backend's name and every rank's device ordinal (gathered through that same backend)."""
+    import torch
+    if dist is None:
+        return {"rccl_ranks": 1, "backend": "none", "device_ordinals": [local_device]}
+    backend = dist.get_backend()
+    t = torch.zeros(world, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+    t[dist.get_rank()] = local_device + 1
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return {"rccl_ranks": dist.get_world_size(), "backend": "nccl (RCCL)" if backend == "nccl" else backend,
+            "device_ordinals": [int(v) - 1 for v in t.cpu().tolist()]}
+
+
 def init_dist(args):
-    """(rank, local_rank, world, dist or None).  One process per GPU, launched by torch.distributed.run for N > 1."""
+    """(rank, local_rank, world, dist or None).  One process per GPU; main() has already started the ranks when needed."""
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
-        args.gpus = world
+        if args.gpus != 1:
+            sys.exit(f"bench.py: WORLD_SIZE {world} does not match --gpus {args.gpus}")
+        args.gpus = world  # started by torch.distributed.run without --gpus: take the launcher's word
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (no CPU fallback for the NMI path)")
     if args.all_on_device0:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} wants device {local_rank}, only {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.force_dist:
@@ -187,12 +286,13 @@ def run_stream_config(args):
     centre = 13 * 27 + 13
     if not (table[..., 0] == centre).all():
         sys.exit(f"rank {rank}: stream config: unexpected winners {sorted(set(table[..., 0].reshape(-1).tolist()))}")
+    evidence = rank_evidence(world, dist, local_rank)
     if rank == 0:
         evals = n_kf * levels * 729
         h2d = n_kf * levels * (27 + 1) * w * h
         print(json.dumps({"metric": "keyframes/s (BASELINE configs[4]: 848x480, 3 levels x 729 candidates, render stacks streamed H2D)",
                           "value": n_kf / dt, "unit": "keyframes/s", "evals_per_s": evals / dt, "n_gpus": world,
-                          "keyframes": n_kf, "levels": levels, "h2d_GBps_all_ranks": h2d / dt / 1e9, "data": "synthetic",
+                          "keyframes": n_kf, "levels": levels, "h2d_GBps_all_ranks": h2d / dt / 1e9, "data": "synthetic", **evidence,
                           "higher_is_better": True, "scaling": "strong",
                           "config": {"workload": "BASELINE.json configs[4]: 100-keyframe sequence, coarse-to-fine 3 levels, double-buffered render stacks",
                                      "width": w, "height": h, "pipeline_depth": 2,
@@ -269,10 +369,11 @@ def run_e2e_config(args):
     dt, table = timed_region(lambda: sharding.run_keyframes(n_kf, levels, rank, world, lambda kf: keyframe(), dist, red_dev), dist)
     if not (table[:, 0, 0] == 13 * 27 + 13).all():
         sys.exit(f"rank {rank}: e2e config: a coarse level lost the centre cell")
+    evidence = rank_evidence(world, dist, local_rank)
     if rank == 0:
         print(json.dumps({"metric": "keyframes/s (device end to end: 848x480, 3 levels x (27 cloud renders + 27 warps + 729-candidate search))",
                           "value": n_kf / dt, "unit": "keyframes/s", "evals_per_s": n_kf * levels * 729 / dt,
-                          "n_gpus": world, "points": int(xyz.shape[0]), "data": "synthetic",
+                          "n_gpus": world, "points": int(xyz.shape[0]), "data": "synthetic", **evidence,
                           "ms_per_level_per_rank": dt / n_kf / levels * 1e3 * world,
                           "hip_graph": level is not None, "higher_is_better": True, "scaling": "strong",
                           "config": {"workload": "BASELINE.json configs[4] shape with the render / warp producers on the device",
@@ -312,7 +413,15 @@ def main():
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo; numbers are meaningless)")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--cpu-threads", type=int, default=16, help="cap on oracle threads for the cpu_baseline leg")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="start the ranks, have each report its rendezvous and the device it would select, touch no GPU, exit")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:  # plain `python3 bench.py --gpus N`: we are the launcher
+        sys.exit(self_launch(args, sys.argv[1:]))
+    if args.dry_launch:
+        sys.exit(dry_launch(args))
     if args.config == "stream":
         return run_stream_config(args)
     if args.config == "e2e":
@@ -490,6 +599,7 @@ def main():
     else:
         kernel_ms = kernel_ms_exclusive
 
+    evidence = rank_evidence(world, dist, local_rank)
     if rank == 0:
         evals_per_step = S_total * WN
         per_launch_evals = S_PER_RANK * WN
@@ -497,12 +607,16 @@ def main():
         out = {
             "metric": f"pose-candidate NMI evals/sec ({WIDTH}x{HEIGHT}, 256 bins)" +
                       (", one blocking nmi_search_grid call per step (SURVEY.md 8d)" if args.blocking else
-                       ", throughput mode: steps enqueued back to back, every winner read back and checked in the timed region"),
+                       ", throughput mode: steps enqueued back to back, every winner read back and checked in the timed region") +
+                      (f"; beside the W warm-up steps an untimed clock warm-up of clock_warmup_ms = {args.clock_warmup_ms:g} ms precedes the timed region"
+                       if args.clock_warmup_ms > 0 else ""),
+            "extra_warmup": "clock_warmup_ms",
             "value": evals_per_step * args.steps / elapsed,
             # SURVEY.md 8(d) defines the metric on ONE blocking nmi_search_grid call including its 8-byte read-back:
             "blocking_call_evals_per_s": per_launch_evals / (blocking_call_ms * 1e-3),
             "unit": "evals/s",
             "n_gpus": world,
+            **evidence,
             "steps": args.steps,
             "warmup": args.warmup,
             "clock_warmup_ms": args.clock_warmup_ms,
@@ -525,6 +639,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_pmc_traffic() if args.config == "c2" else None,
                          "lds": load_pmc_lds() if args.config == "c2" else None,
+                         "static": static_profile_stamp() if args.config == "c2" else None,
                          "note": "frac is the contract's ALGORITHMIC fraction (2*W*H+4 bytes per evaluation / kernel time / 8 TB/s); "
                                  "the inputs live in L2 / Infinity Cache (traffic) and the kernel is bound by LDS atomic issue, see lds",
                          "kernel": "nmi_grid_kernel", "kernel_ms": kernel_ms, "kernel_ms_exclusive": kernel_ms_exclusive,

@@ -58,9 +58,15 @@ WORKER = textwrap.dedent("""
         rs = np.full_like(rs, 255)
     if case == "warpaxis":   # fewer renders than ranks: the warp axis is sharded instead (SURVEY.md 8e)
         rs = rs[:world - 1] if world > 1 else rs[:1]
+    if case == "c4shape":    # BASELINE.json configs[3]: 512 renders (8^3) x 64 warps (4^3) = 32,768 candidates over 8 ranks, tiny images
+        wl = sy.workload(24, 16, 512, 64, seed=11)
+        rs, ws = wl["render_stack"], wl["warp_stack"]
     S, Wn = rs.shape[0], ws.shape[0]
     off, cnt, woff, wcnt = sharding.grid_shard(S, Wn, rank, world)
     assert (case == "warpaxis") == (wcnt != Wn or world == 1)
+    if case == "c4shape":
+        assert (off, cnt, woff, wcnt) == (64 * rank, 64, 0, 64) and world == 8
+        assert sharding.keyframe_share(100, rank, world) == list(range(rank, 100, 8))   # configs[4] dealt over the same ranks
     if cnt and wcnt:
         local, _, _ = oc.search_grid(rs[off:off + cnt], ws[woff:woff + wcnt])
     else:
@@ -68,7 +74,14 @@ WORKER = textwrap.dedent("""
     key = torch.tensor([sharding.local_key_from_ratings(local, off, S, woff)], dtype=torch.int64)
     sharding.allreduce_key(key, dist)
     got = capi.key_unpack(int(key.item()))
-    full, idx, best = oc.search_grid(rs, ws)
+    if case == "c4shape" and rank:   # the unsharded table is computed once, on rank 0
+        ref = [None]
+        dist.broadcast_object_list(ref, src=0)
+        full, idx, best = ref[0]
+    else:
+        full, idx, best = oc.search_grid(rs, ws, threads=1 if case != "c4shape" else 2)
+        if case == "c4shape":
+            dist.broadcast_object_list([(full, idx, best)], src=0)
     assert got == (idx, best), (rank, got, idx, best)
     # the gathered blocks reassemble the full rating table (optional all-gather of SURVEY.md 8e)
     parts = [None] * world
@@ -87,7 +100,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,case", [(2, "planted"), (2, "ties"), (2, "allzero"), (3, "planted"), (3, "warpaxis")])
+@pytest.mark.parametrize("world,case", [(2, "planted"), (2, "ties"), (2, "allzero"), (3, "planted"), (3, "warpaxis"), (8, "c4shape")])
 def test_sharded_argmax_over_gloo(world, case, tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
@@ -95,7 +108,7 @@ def test_sharded_argmax_over_gloo(world, case, tmp_path):
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   NMI_ROOT=ROOT, NMI_CASE=case, OMP_NUM_THREADS="2")
+                   NMI_ROOT=ROOT, NMI_CASE=case, OMP_NUM_THREADS="2" if world < 8 else "1")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
     for p in procs:

@@ -5,6 +5,9 @@ pmc_traffic.json (HBM-side bytes per launch with the gfx950 FETCH_SIZE correctio
 import csv, glob, json, os, shutil, statistics as st, sys
 
 out = sys.argv[1]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # kernel_source_id(): the stamp that ties a counter profile to the kernel sources it was taken on
+SRC_ID = bench.kernel_source_id()
 summary = {}
 for name in ("pmc_fetch", "pmc_write", "pmc_lds"):
     files = glob.glob(os.path.join(out, name, "*", "*_counter_collection.csv"))
@@ -31,7 +34,7 @@ if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
     write = summary["WRITE_SIZE"]["mean"] * 1024
     json.dump({"hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected_x2": fetch, "write_bytes": write,
                "note": "L2-fabric side counters (TCC_EA0): Infinity-Cache hits are included, so this is an upper bound on HBM bytes",
-               "source": os.path.basename(out)}, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+               "source": os.path.basename(out), "kernel_source_sha16": SRC_ID}, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 if "SQ_LDS_IDX_ACTIVE" in summary and "SQ_INSTS_LDS" in summary:
     # LDS side of the dominant kernel (what actually bounds it).  SQ counters tick in units of 4 cycles
     # summed over the CUs' SIMDs.  Conflict-free reference: a 64-lane ds_add_u32 is served as 2 groups of 32 lanes, one
@@ -45,7 +48,7 @@ if "SQ_LDS_IDX_ACTIVE" in summary and "SQ_INSTS_LDS" in summary:
                "conflict_free_cycles_per_wave_instruction": 2.0,
                "note": "SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT / SQ_INSTS_LDS per launch of nmi_grid_kernel (rocprofv3 --pmc, own pass); "
                        "conflict-free rate from MI355X_MICROARCH.md section LDS (2 x 32 lanes, one LDS-array cycle per group)",
-               "source": os.path.basename(out)}, open(os.path.join(out, "pmc_lds.json"), "w"), indent=1)
+               "source": os.path.basename(out), "kernel_source_sha16": SRC_ID}, open(os.path.join(out, "pmc_lds.json"), "w"), indent=1)
 for cfg in ("c3", "c4"):
     stats = glob.glob(os.path.join(out, "trace_" + cfg, "*", "*_kernel_stats.csv"))
     if stats:
