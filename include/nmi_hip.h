@@ -76,8 +76,12 @@ int nmi_params_default(nmi_params *p, int32_t width, int32_t height);
  * Tracking thread only, src/Tracking.cc:1886).  Several contexts may search at the same time from several threads; if they
  * score SMALL grids (up to 64 candidates) concurrently, give each a share of the device with NMI_OPT_WORKGROUPS
  * (e.g. compute units / number of contexts): the split kernel used for small grids wants all workgroups of a launch
- * resident at once, and two such launches that together exceed the device make each other wait until a 30 ms guard
- * ends the wait and the calls are redone by the other kernel (correct results, one slow call, split forms off afterwards).
+ * resident at once, and two such launches that together exceed the device (or a neighbour -- another process, a GL or
+ * compute client of the same GPU -- holding compute units) make each other wait until a 2 ms guard ends the wait.  The
+ * search of THAT launch is then redone by the one-workgroup-per-candidate kernel (correct results, one slow call) and the
+ * split forms pause for the next 16 small-grid launches of the context -- 32, 64, ... 4096 when the retry times out again --
+ * after which they are used again; nmi_split_status reports the state.  Calls that only enqueue (h_key == NULL) never use
+ * the split kernel: nobody would look for its timeout.
  */
 int nmi_create(const nmi_params *params, nmi_ctx **out_ctx);
 int nmi_destroy(nmi_ctx *ctx);
@@ -236,6 +240,27 @@ int nmi_level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int64
 int nmi_level_create_mesh(nmi_ctx *ctx, const float *d_xyz, const float *d_uv, int64_t n_triangles, const nmi_texture *tex,
                           const uint8_t *d_frame, int32_t S, int32_t Wn, nmi_level **out);
 int nmi_level_run(nmi_level *lv, const float *h_mvps, const double *h_forward, int64_t *h_best_index, float *h_best_score);
+/*
+ * Level sharded over ranks (new; SURVEY.md 8e applied to the device-side level -- the LATENCY form of BASELINE.json configs[4]:
+ * keyframes of a live sequence are not independent, each search is seeded from the drift since the previous NMI fix,
+ * src/Tracking.cc:2001-2053, inside the sequential Track(), :598-616, so a live level can only be made faster by sharing ITS
+ * candidates).  A _block level covers renders [s_offset, s_offset + S_local) x warps [w_offset, w_offset + Wn_local) of an
+ * S_total x Wn_total level: the rank renders only its S_local views (h_mvps [S_local][16]), warps the frame Wn_local times
+ * (h_forward [Wn_local][9]) and scores its cells with GLOBAL linear indices w * S_total + s.  Either count may be 0 (more
+ * ranks than cells on the sharded axis): the rank then only takes part in the exchange.  nmi_level_run on a block returns
+ * the block's own winner (for callers that reduce the keys themselves, e.g. torch.distributed over gloo: nmi_key_pack);
+ * nmi_level_run_rccl adds the level's only exchange -- ncclAllReduce(ncclMax, ncclUint64) of the 8-byte key on the
+ * context's stream, out of place -- and returns the level's winner on every rank.  Every rank of the communicator must
+ * call it once per level.
+ */
+int nmi_level_create_block(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int64_t n_points, const uint8_t *d_frame,
+                           int32_t S_local, int32_t s_offset, int32_t S_total, int32_t Wn_local, int32_t w_offset, int32_t Wn_total,
+                           float point_size, nmi_level **out);
+int nmi_level_create_mesh_block(nmi_ctx *ctx, const float *d_xyz, const float *d_uv, int64_t n_triangles, const nmi_texture *tex,
+                                const uint8_t *d_frame, int32_t S_local, int32_t s_offset, int32_t S_total, int32_t Wn_local,
+                                int32_t w_offset, int32_t Wn_total, nmi_level **out);
+int nmi_level_run_rccl(nmi_level *lv, const float *h_mvps, const double *h_forward, void *nccl_comm, int64_t *h_best_index,
+                       float *h_best_score);
 /* Host copies of what the latest nmi_level_run produced: the S renders [S][H][W], the Wn warps [Wn][H][W] and the rating
  * table [Wn][S] (any pointer may be NULL).  Blocking; for tests and debugging (the reference's orb_prop_log dumps,
  * src/Tracking.cc:1911-1948, serve the same purpose). */
@@ -252,12 +277,24 @@ int nmi_level_destroy(nmi_level *lv);
  * A slot is reused by submission i + depth only after ticket i was waited for.  h_* buffers must stay valid (and should be
  * page-locked, e.g. hipHostMalloc) until the ticket completes.  Passing h_frame == NULL re-uses the warp stack produced by
  * the most recent submission that had a frame.
+ * A ticket whose small grid timed out in the split kernel (see nmi_create) is redone inside nmi_stream_wait when its warp
+ * stack is still on the device; when a later frame has replaced it the wait returns NMI_ERR_NOT_READY, the ticket's rating
+ * table is withheld (nmi_stream_copy_ratings fails) and the caller submits that level again.
  */
 typedef struct nmi_stream nmi_stream;
 int nmi_stream_create(nmi_ctx *ctx, int32_t max_S, int32_t max_Wn, int32_t depth, nmi_stream **out);
 int nmi_stream_destroy(nmi_stream *st);
 int nmi_stream_submit(nmi_stream *st, const uint8_t *h_render_stack, int32_t S, const uint8_t *h_frame,
                       const double *h_forward, int32_t Wn, int64_t *ticket);
+/* Block form for a level sharded over ranks (see nmi_level_create_block): this rank uploads and scores only renders
+ * [s_offset, s_offset + S_local) of the level's S_total (the H2D traffic that bounds the streamed form is divided by the
+ * number of ranks) against warps [w_offset, w_offset + Wn_local) of Wn_total, which it makes locally from the frame;
+ * h_forward holds the Wn_local homographies of its block.  With nccl_comm != NULL the key is MAX-all-reduced on the compute
+ * stream right behind the search (every rank submits the levels in the same order) and the ticket completes with the
+ * level's winner; with NULL it completes with the block's own key.  S_local may be 0 (h_render_stack may then be NULL). */
+int nmi_stream_submit_block(nmi_stream *st, const uint8_t *h_render_stack, int32_t S_local, int32_t s_offset, int32_t S_total,
+                            const uint8_t *h_frame, const double *h_forward, int32_t Wn_local, int32_t w_offset, int32_t Wn_total,
+                            void *nccl_comm, int64_t *ticket);
 int nmi_stream_wait(nmi_stream *st, int64_t ticket, int64_t *h_best_index, float *h_best_score);
 /* Optional rating tables: after nmi_stream_keep_ratings(st, 1) every submission also stores its [Wn][S] table in its slot;
  * nmi_stream_copy_ratings copies the table of a ticket that has been waited for (n = Wn * S floats), valid until the
@@ -305,7 +342,7 @@ int nmi_last_kernel_ms(nmi_ctx *ctx, float *h_ms);
                                   wavefront role; exact but slower) exist only in a library built with
                                   -DNMI_BUILD_ABLATIONS (NMI_ERR_UNSUPPORTED otherwise). */
 #define NMI_OPT_PHASE_MASK 2   /* bit 0 histogram phase, bit 1 decode + score, bit 2 disable the flat-chunk shortcut; default 3.
-                                  Bit 9 (tests): one part of the split kernel withholds its hand-off, so the bounded wait of
+                                  Bit 9 (tests): one part of the split kernel withholds its hand-off, so the bounded wait (2 ms) of
                                   the scoring workgroup times out and the call is redone by the one-workgroup kernel. */
 #define NMI_OPT_WORKGROUPS 3   /* workgroups per launch; 0 = one per compute unit (default) */
 #define NMI_OPT_RESULT_PATH 4  /* how the 8-byte winner reaches the host: 1 the kernel posts it to pinned host memory
@@ -341,6 +378,12 @@ int nmi_last_kernel_ms(nmi_ctx *ctx, float *h_ms);
 #define NMI_OPT_STAMPS 9       /* profiling tools only: value = device pointer to uint64 [workgroups][8]; workgroups of the
                                   split kernel store wall-clock stamps (100 MHz) at their phase boundaries there; 0 = off */
 int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value);
+
+/* Split-kernel liveness (see nmi_create): *timeouts = hand-off timeouts so far, *cooldown_calls_left = small-grid launches
+ * that will still go through the one-workgroup kernel before the split forms are tried again, *next_cooldown = length of
+ * the pause the next timeout would start, *last_launch_parts = row parts per candidate of the most recent launch (0: the
+ * one-workgroup kernel scored it).  Any pointer may be null.  Does not wait. */
+int nmi_split_status(nmi_ctx *ctx, int32_t *timeouts, int32_t *cooldown_calls_left, int32_t *next_cooldown, int32_t *last_launch_parts);
 
 /* Introspection. */
 /* Copies the context's per-count term table, term[c] = (c/len) * log2(c/len) in the reference's fp32 form with

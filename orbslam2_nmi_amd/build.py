@@ -49,28 +49,50 @@ def is_stale():
 ABLATE_LIB = os.path.join(LIB_DIR, "libnmi_hip_ablate.so")
 
 
-def command(ablations=False):
-    return ["hipcc", "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared", "-ffp-contract=off",
-            "-Wall", "-Wno-unused-function", *(["-DNMI_BUILD_ABLATIONS"] if ablations else []),
-            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"), "-I" + os.path.join(PKG, "host"),
-            *sources(), "-o", ABLATE_LIB if ablations else LIB, "-ldl"]
+def flags(ablations=False):
+    return ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+            *(["-DNMI_BUILD_ABLATIONS"] if ablations else []),
+            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"), "-I" + os.path.join(PKG, "host")]
+
+
+def compile_and_link(out, ablations=False, force=False, verbose=False, jobs=None):
+    """One object per source under lib/obj/ (recompiled when the source or any header is newer), compiled in parallel, then
+    one link.  Same flags for every translation unit; no relocatable device code (no kernel calls across units)."""
+    from concurrent.futures import ThreadPoolExecutor
+    obj_dir = os.path.join(LIB_DIR, "obj_ablate" if ablations else "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    newest_header = max(os.path.getmtime(f) for f in headers() + [os.path.abspath(__file__)])
+    todo, objs = [], []
+    for src in sources():
+        obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
+            todo.append(["hipcc", *flags(ablations), "-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+
+    if todo:
+        with ThreadPoolExecutor(max_workers=jobs or min(6, os.cpu_count() or 1)) as ex:
+            list(ex.map(run, todo))
+    run(["hipcc", "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", out, "-ldl"])
+    return out
 
 
 def build(force=False, verbose=False):
     """Compile the library if sources are newer than the binary.  Returns the library path."""
     if force or is_stale():
         os.makedirs(LIB_DIR, exist_ok=True)
-        cmd = command()
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
+        compile_and_link(LIB, force=force, verbose=verbose)
     return LIB
 
 
 if __name__ == "__main__":
     if "--ablations" in sys.argv:
         os.makedirs(LIB_DIR, exist_ok=True)
-        subprocess.check_call(command(ablations=True))
+        compile_and_link(ABLATE_LIB, ablations=True, verbose=True)
         print(ABLATE_LIB)
     else:
         print(build(force="--force" in sys.argv, verbose=True))

@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = (
     "nmi_stream_submit", "nmi_stream_wait", "nmi_stream_keep_ratings", "nmi_stream_copy_ratings", "nmi_key_pack", "nmi_key_unpack", "nmi_search_grid_rccl", "nmi_search_grid_block_rccl",
     "nmi_rccl_unique_id", "nmi_rccl_comm_init", "nmi_rccl_comm_destroy", "nmi_set_profiling", "nmi_last_kernel_ms",
     "nmi_set_option", "nmi_copy_term_table", "nmi_abi_version", "nmi_error_string", "nmi_last_error_detail", "nmi_get_info", "nmi_last_content", "nmi_sort_points", "nmi_sort_triangles",
+    "nmi_split_status", "nmi_level_create_block", "nmi_level_create_mesh_block", "nmi_level_run_rccl", "nmi_stream_submit_block",
 )
 
 
@@ -91,6 +92,10 @@ def load_library(build_if_missing=False):
     lib.nmi_level_create.argtypes = [vp, vp, vp, C.c_int64, vp, i32, i32, C.c_float, C.POINTER(vp)]
     lib.nmi_level_create_mesh.argtypes = [vp, vp, vp, C.c_int64, vp, vp, i32, i32, C.POINTER(vp)]
     lib.nmi_level_run.argtypes = [vp, f32p, C.POINTER(C.c_double), i64p, f32p]
+    lib.nmi_level_create_block.argtypes = [vp, vp, vp, C.c_int64, vp, i32, i32, i32, i32, i32, i32, C.c_float, C.POINTER(vp)]
+    lib.nmi_level_create_mesh_block.argtypes = [vp, vp, vp, C.c_int64, vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(vp)]
+    lib.nmi_level_run_rccl.argtypes = [vp, f32p, C.POINTER(C.c_double), vp, i64p, f32p]
+    lib.nmi_stream_submit_block.argtypes = [vp, vp, i32, i32, i32, vp, C.POINTER(C.c_double), i32, i32, i32, vp, i64p]
     lib.nmi_level_copy_outputs.argtypes = [vp, vp, vp, vp]
     lib.nmi_level_destroy.argtypes = [vp]
     lib.nmi_stream_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
@@ -117,6 +122,7 @@ def load_library(build_if_missing=False):
     lib.nmi_last_error_detail.restype = C.c_char_p
     lib.nmi_get_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     lib.nmi_last_content.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    lib.nmi_split_status.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     lib.nmi_sort_points.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
     lib.nmi_sort_triangles.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
     _lib = lib
@@ -271,6 +277,12 @@ class NmiContext:
         f, r, w = C.c_int32(0), C.c_int32(0), C.c_int32(0)
         self._check(self._lib.nmi_last_content(self._h, C.byref(f), C.byref(r), C.byref(w)), "nmi_last_content")
         return {"few_levels": bool(f.value), "nr": r.value, "nw": w.value}
+
+    def split_status(self):
+        """Split-kernel liveness -> {"timeouts", "cooldown_calls_left", "next_cooldown", "last_launch_parts"} (nmi_split_status)."""
+        v = [C.c_int32(0) for _ in range(4)]
+        self._check(self._lib.nmi_split_status(self._h, *[C.byref(x) for x in v]), "nmi_split_status")
+        return dict(zip(("timeouts", "cooldown_calls_left", "next_cooldown", "last_launch_parts"), (x.value for x in v)))
 
     def term_table(self):
         """The per-count entropy-term table (NMI.cu:242-263 evaluated once per possible count) as numpy float32 [W*H+1]."""
@@ -500,29 +512,45 @@ class NmiTexture:
 class NmiLevel:
     """nmi_level wrapper: cloud + frame -> renders, warps, search, winner as one captured HIP graph."""
 
-    def __init__(self, ctx, xyz, red, frame, S, Wn, point_size, texture=None):
+    def __init__(self, ctx, xyz, red, frame, S, Wn, point_size, texture=None, block=None):
         """Point cloud: xyz [N,3], red [N], point_size.  Textured mesh: pass texture=NmiTexture, xyz [3T,3] corner
-        positions and `red` = uv [3T,2] (point_size is ignored)."""
+        positions and `red` = uv [3T,2] (point_size is ignored).
+        block = (s_offset, S_total, w_offset, Wn_total): this level is one rank's block (S views x Wn warps, either may be 0)
+        of a level sharded over ranks (nmi_level_create_block); winners then carry global indices."""
         self.ctx, self._lib = ctx, ctx._lib
         self._keep = (xyz, red, frame, texture)  # the graph holds their device addresses
         self.S, self.Wn = int(S), int(Wn)
         self._h = C.c_void_p()
         ctx._order_after_torch()
+        if block is None:
+            block = (0, self.S, 0, self.Wn)
+        so, st, wo, wt = (int(v) for v in block)
         if texture is None:
-            ctx._check(self._lib.nmi_level_create(ctx._h, xyz.data_ptr(), red.data_ptr(), xyz.shape[0], frame.data_ptr(), self.S,
-                                                  self.Wn, float(point_size), C.byref(self._h)), "nmi_level_create")
+            ctx._check(self._lib.nmi_level_create_block(ctx._h, xyz.data_ptr(), red.data_ptr(), xyz.shape[0], frame.data_ptr(), self.S, so,
+                                                        st, self.Wn, wo, wt, float(point_size), C.byref(self._h)), "nmi_level_create_block")
         else:
-            ctx._check(self._lib.nmi_level_create_mesh(ctx._h, xyz.data_ptr(), red.data_ptr(), xyz.shape[0] // 3, texture._h,
-                                                       frame.data_ptr(), self.S, self.Wn, C.byref(self._h)), "nmi_level_create_mesh")
+            ctx._check(self._lib.nmi_level_create_mesh_block(ctx._h, xyz.data_ptr(), red.data_ptr(), xyz.shape[0] // 3, texture._h,
+                                                             frame.data_ptr(), self.S, so, st, self.Wn, wo, wt, C.byref(self._h)),
+                       "nmi_level_create_mesh_block")
 
-    def run(self, mvps, homographies):
+    def _params(self, mvps, homographies):
         m = np.ascontiguousarray(mvps, np.float32).reshape(-1)
         h = np.ascontiguousarray(homographies, np.float64).reshape(-1)
         assert m.size == self.S * 16 and h.size == self.Wn * 9
+        return m, h, (m.ctypes.data_as(C.POINTER(C.c_float)) if m.size else None), (h.ctypes.data_as(C.POINTER(C.c_double)) if h.size else None)
+
+    def run(self, mvps, homographies):
+        """mvps [S,16], homographies [Wn,3,3] of THIS block -> (global index, score) of the block's winner."""
+        m, h, mp, hp = self._params(mvps, homographies)
         idx, sc = C.c_int64(0), C.c_float(0)
-        self.ctx._check(self._lib.nmi_level_run(self._h, m.ctypes.data_as(C.POINTER(C.c_float)),
-                                                h.ctypes.data_as(C.POINTER(C.c_double)), C.byref(idx), C.byref(sc)),
-                        "nmi_level_run")
+        self.ctx._check(self._lib.nmi_level_run(self._h, mp, hp, C.byref(idx), C.byref(sc)), "nmi_level_run")
+        return int(idx.value), np.float32(sc.value)
+
+    def run_rccl(self, mvps, homographies, comm):
+        """The same + the level's MAX all-reduce over the RCCL communicator -> the LEVEL's winner, on every rank."""
+        m, h, mp, hp = self._params(mvps, homographies)
+        idx, sc = C.c_int64(0), C.c_float(0)
+        self.ctx._check(self._lib.nmi_level_run_rccl(self._h, mp, hp, comm, C.byref(idx), C.byref(sc)), "nmi_level_run_rccl")
         return int(idx.value), np.float32(sc.value)
 
     def outputs(self):
@@ -557,8 +585,10 @@ class NmiStream:
                    "nmi_stream_create")
         self._keep = {}
 
-    def submit(self, render_stack_host, frame_host=None, homographies=None):
-        """render_stack_host / frame_host: pinned CPU uint8 torch tensors; homographies: float64 [Wn,3,3] (with a frame)."""
+    def submit(self, render_stack_host, frame_host=None, homographies=None, block=None, comm=None):
+        """render_stack_host / frame_host: pinned CPU uint8 torch tensors; homographies: float64 [Wn,3,3] (with a frame).
+        block = (s_offset, S_total, w_offset, Wn_total): the stack and the homographies are this rank's block of a level
+        sharded over ranks (nmi_stream_submit_block); comm: RCCL communicator whose ranks all-reduce the level's key."""
         rs = render_stack_host
         if rs.is_cuda or rs.dtype.__str__() != "torch.uint8" or not rs.is_contiguous():
             raise TypeError("render_stack_host must be a contiguous CPU uint8 tensor (pinned for overlap)")
@@ -567,8 +597,13 @@ class NmiStream:
             m = np.ascontiguousarray(homographies, np.float64).reshape(-1, 9)
             fp, mp, wn = frame_host.data_ptr(), m.ctypes.data_as(C.POINTER(C.c_double)), m.shape[0]
         t = C.c_int64(-1)
-        self.ctx._check(self._lib.nmi_stream_submit(self._h, rs.data_ptr(), rs.shape[0], fp, mp, wn, C.byref(t)),
-                        "nmi_stream_submit")
+        if block is None and comm is None:
+            self.ctx._check(self._lib.nmi_stream_submit(self._h, rs.data_ptr(), rs.shape[0], fp, mp, wn, C.byref(t)),
+                            "nmi_stream_submit")
+        else:
+            so, st, wo, wt = (int(v) for v in block)
+            self.ctx._check(self._lib.nmi_stream_submit_block(self._h, rs.data_ptr() if rs.shape[0] else None, rs.shape[0], so, st, fp, mp,
+                                                              wn, wo, wt, comm, C.byref(t)), "nmi_stream_submit_block")
         self._keep[t.value] = (rs, frame_host, m)  # keep host buffers alive until the ticket completes
         return int(t.value)
 

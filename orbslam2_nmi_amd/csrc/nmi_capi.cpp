@@ -82,6 +82,7 @@ static void choose_split(const nmi_ctx *ctx, int64_t total, int cap, int *parts,
 {
     *parts = 0;
     *pix_parts = 1;
+    if (cap > ctx->compute_units) cap = ctx->compute_units;  // all workgroups of a split launch must be resident at once
     if (ctx->hist_variant != 3 || ctx->split_mode == 0 || total <= 0 || total > cap) return;
     auto fits = [&](int k, int p) { return nmi::split_workgroups((int)total, k, p) <= cap; };
     auto exists = [](int k, int p) { return p == 1 || (k == 8 && (p == 2 || p == 4)) || (k == 4 && p == 2); };
@@ -190,6 +191,8 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     // Only launches whose winner the host will poll for post to the mailbox (one bit of sequence is enough
     // because those calls are blocking, hence strictly alternating).  The sequence numbers, the key-slot flip and the
     // "posted" flag are committed only once the launch has been accepted: a failed launch leaves the protocol in step.
+    // does somebody look for a split-kernel timeout after this launch?  (blocking calls, nmi_eval_pairs, stream tickets, RCCL form)
+    const bool split_checked = post || post_score || ctx->allow_unchecked_split || ctx->pair_renders != nullptr;
     post = post && ctx->result_path == 1;
     post_score = post_score && ctx->result_path == 1;
     a.mailbox = post ? ctx->mailbox : nullptr;
@@ -217,14 +220,23 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
         }
         ctx->posted = post;
         ctx->last_slot = ctx->slot;
+        ctx->last_parts = 0;
+        ctx->last_epoch = 0;
         return NMI_OK;
     }
     const int cap = ctx->workgroups > 0 ? ctx->workgroups : ctx->compute_units;
     int parts = 0, pix_parts = 1;
     // the split kernel's consumers wait for their producers inside the launch: all its workgroups must be able to run at
     // once, i.e. no more of them than compute units (each takes a whole CU)
-    choose_split(ctx, total, cap < ctx->compute_units ? cap : ctx->compute_units, &parts, &pix_parts);
+    choose_split(ctx, total, cap, &parts, &pix_parts);
     if (pix_parts > 1 && ctx->npix >= (1 << 24)) pix_parts = 1;  // block granules hold 24-bit counts
+    if (parts && !split_checked) parts = 0;  // enqueue-only call: nobody would notice a timed-out hand-off, so no split kernel
+    if (parts && ctx->split_cooldown > 0) {  // after a timeout: nmi_grid_kernel for a while, then the split forms again
+        --ctx->split_cooldown;
+        parts = 0;
+    }
+    if (!parts) pix_parts = 1;
+    if (ctx->pair_renders && !parts) return NMI_ERR_UNSUPPORTED;  // per-pair pointers exist in the split kernel only (nmi_eval_pairs decides first)
     int workgroups = (int)(total < cap ? total : cap);
     if (parts) {
         int rs = ensure_slabs(ctx, (int)total);
@@ -315,6 +327,7 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     ctx->last_slot = ctx->slot;
     ctx->slot ^= 1;
     ctx->last_parts = parts;
+    ctx->last_epoch = parts ? a.epoch : 0;
     if (ctx->profiling) {
         NMI_HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
         ctx->have_timing = true;
@@ -325,17 +338,27 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
 // A hand-off of the split kernel timed out (its workgroups could not all run at once -- e.g. the device exposes fewer
 // compute units to this process than it reports): wait for the launch to drain, switch the split forms off for this
 // context and tell the caller to redo the call, which then goes through nmi_grid_kernel.
-bool split_timed_out(nmi_ctx *ctx)
+bool split_launch_failed(nmi_ctx *ctx, int parts, uint32_t epoch)
 {
-    if (!ctx->last_parts || !__atomic_load_n(ctx->h_split_error, __ATOMIC_ACQUIRE)) return false;
+    if (!parts) return false;
+    uint32_t *word = ctx->h_split_error + (epoch & 15u);
+    if (__atomic_load_n(word, __ATOMIC_ACQUIRE) != epoch) {
+        ctx->split_backoff = nmi_ctx::kSplitBackoffMin;  // a split launch that went through: the short cooldown is re-armed
+        return false;
+    }
     (void)hipStreamSynchronize(ctx->stream);
-    *ctx->h_split_error = 0;
-    ctx->split_mode = 0;
+    __atomic_store_n(word, 0u, __ATOMIC_RELEASE);
+    ++ctx->split_timeouts;
+    ctx->split_cooldown = ctx->split_backoff;
+    if (ctx->split_backoff < nmi_ctx::kSplitBackoffMax) ctx->split_backoff *= 2;
     return true;
 }
 
+// Call once the most recent launch's result has arrived (the kernel raises the flag before it posts anything).
+bool split_timed_out(nmi_ctx *ctx) { return split_launch_failed(ctx, ctx->last_parts, ctx->last_epoch); }
+
 // what nmi_last_error_detail says after a call that was redone because of such a timeout (the call itself succeeded)
-static const char *const kSplitTimeoutNote = "split kernel hand-off timed out; call redone without it, split forms disabled for this context";
+static const char *const kSplitTimeoutNote = "split kernel hand-off timed out; call redone by the one-workgroup kernel, split forms paused (nmi_split_status)";
 
 // Polls a pinned host word until (word & mask) == want; *out receives the word.  NMI_OPT_WAIT_MODE 0 spins (lowest
 // latency; occupies the calling core for the duration of the search), 1 yields the core between polls (the Tracking
@@ -531,7 +554,7 @@ int nmi_create(const nmi_params *params, nmi_ctx **out_ctx)
     memset(ctx->score_mailbox, 0, 2 * sizeof(unsigned long long));
     if ((e = hipHostMalloc((void **)&ctx->h_split_error, 64, hipHostMallocCoherent | hipHostMallocMapped)) != hipSuccess)
         return fail(e, "hipHostMalloc(split error)");
-    *ctx->h_split_error = 0;
+    memset(ctx->h_split_error, 0, 64);
     if ((e = hipHostGetDevicePointer((void **)&ctx->d_split_error, ctx->h_split_error, 0)) != hipSuccess)
         return fail(e, "hipHostGetDevicePointer(split error)");
     if ((e = hipHostMalloc((void **)&ctx->h_key, sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
@@ -756,22 +779,34 @@ int nmi_search_grid_block(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S_l
                           const uint8_t *warp_stack, int32_t Wn_local, int32_t w_offset, int32_t Wn_total, float *d_ratings,
                           uint64_t *d_key, uint64_t *h_key)
 {
+    return search_block(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn_local, w_offset, Wn_total, d_ratings, d_key, h_key,
+                        /*caller_checks=*/false);
+}
+
+}  // extern "C"
+
+int nmi_internal::search_block(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S_local, int32_t s_offset, int32_t S_total,
+                               const uint8_t *warp_stack, int32_t Wn_local, int32_t w_offset, int32_t Wn_total, float *d_ratings,
+                               uint64_t *d_key, uint64_t *h_key, bool caller_checks)
+{
     int rc = check_grid_args(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn_local);
     if (rc != NMI_OK) return rc;
     if (w_offset < 0 || Wn_total < Wn_local || w_offset + Wn_local > Wn_total) return NMI_ERR_INVALID_ARGUMENT;
     if ((int64_t)S_total * Wn_total >= 0x7FFFFFFFll) return NMI_ERR_UNSUPPORTED;  // index lives in 32 bits of the key
     const int32_t Wn = Wn_local;
     DeviceGuard guard(ctx->device);
+    ctx->allow_unchecked_split = caller_checks;
     rc = enqueue_grid(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn, d_ratings, (unsigned long long *)d_key,
                       h_key != nullptr, nullptr, nullptr, nullptr, nullptr, w_offset);
+    ctx->allow_unchecked_split = false;
     if (rc != NMI_OK) return rc;
     if (h_key) {
         unsigned long long k = 0;
         rc = fetch_key(ctx, &k);
         if (rc != NMI_OK) return rc;
-        if (split_timed_out(ctx)) {
-            rc = nmi_search_grid_block(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn_local, w_offset, Wn_total, d_ratings,
-                                       d_key, h_key);
+        if (split_timed_out(ctx)) {  // (the cooldown now routes the redo through nmi_grid_kernel)
+            rc = search_block(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn_local, w_offset, Wn_total, d_ratings, d_key,
+                              h_key, false);
             if (rc == NMI_OK) ctx->detail = kSplitTimeoutNote;
             return rc;
         }
@@ -780,6 +815,18 @@ int nmi_search_grid_block(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S_l
         // table may read it right after this call, from any stream, so the table must be complete (and written back).
         if (d_ratings || d_key) NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
+    return NMI_OK;
+}
+
+extern "C" {
+
+int nmi_split_status(nmi_ctx *ctx, int32_t *timeouts, int32_t *cooldown_calls_left, int32_t *next_cooldown, int32_t *last_launch_parts)
+{
+    if (!ctx) return NMI_ERR_INVALID_ARGUMENT;
+    if (timeouts) *timeouts = (int32_t)ctx->split_timeouts;
+    if (cooldown_calls_left) *cooldown_calls_left = (int32_t)ctx->split_cooldown;
+    if (next_cooldown) *next_cooldown = (int32_t)ctx->split_backoff;
+    if (last_launch_parts) *last_launch_parts = ctx->last_parts;
     return NMI_OK;
 }
 
@@ -838,7 +885,19 @@ int nmi_eval_pairs(nmi_ctx *ctx, const uint8_t *const *h_renders, const uint8_t 
     ctx->detail.clear();
     if (n == 0) return NMI_OK;
     DeviceGuard guard(ctx->device);
-    if (ctx->hist_variant != 3 || ctx->split_mode == 0) {  // split forms unavailable: one pair at a time
+    // launches of at most compute_units / 4 pairs (4 row parts each); small batches get more parts per pair
+    const int min_parts = ctx->split_mode > 0 ? ctx->split_mode : 4;
+    const int cus = ctx->workgroups > 0 && ctx->workgroups < ctx->compute_units ? ctx->workgroups : ctx->compute_units;
+    const int per_launch = cus / min_parts > 0 ? ((cus / min_parts) & ~7) > 0 ? (cus / min_parts) & ~7 : 1 : 1;
+    // Decided BEFORE anything is launched: does a split form exist for every chunk of this batch (none does with
+    // NMI_OPT_WORKGROUPS below 16, with NMI_OPT_SPLIT 0, or while the split forms are paused after a timeout)?
+    bool split_ok = ctx->hist_variant == 3 && ctx->split_mode != 0 && ctx->split_cooldown == 0;
+    for (int off = 0; split_ok && off < n; off += per_launch) {
+        int parts = 0, pix = 1;
+        choose_split(ctx, n - off < per_launch ? n - off : per_launch, ctx->workgroups > 0 ? ctx->workgroups : ctx->compute_units, &parts, &pix);
+        split_ok = parts != 0;
+    }
+    if (!split_ok) {  // one pair at a time (nmi_eval_pair consumes the cooldown)
         for (int i = 0; i < n; ++i) {
             const int rc = nmi_eval_pair(ctx, h_renders[i], h_warps[i], &h_scores[i]);
             if (rc != NMI_OK) return rc;
@@ -865,10 +924,7 @@ int nmi_eval_pairs(nmi_ctx *ctx, const uint8_t *const *h_renders, const uint8_t 
         ctx->h_pair_table[i] = h_renders[i];
         ctx->h_pair_table[ctx->pairs_cap + i] = h_warps[i];
     }
-    // launches of at most compute_units / 4 pairs (4 row parts each); small batches get more parts per pair
-    const int min_parts = ctx->split_mode > 0 ? ctx->split_mode : 4;
-    const int cus = ctx->workgroups > 0 && ctx->workgroups < ctx->compute_units ? ctx->workgroups : ctx->compute_units;
-    const int per_launch = cus / min_parts > 0 ? ((cus / min_parts) & ~7) > 0 ? (cus / min_parts) & ~7 : 1 : 1;
+    uint32_t first_epoch = 0, n_launches = 0;
     for (int off = 0; off < n; off += per_launch) {
         const int m = n - off < per_launch ? n - off : per_launch;
         ctx->pair_renders = ctx->d_pair_table + off;
@@ -878,12 +934,15 @@ int nmi_eval_pairs(nmi_ctx *ctx, const uint8_t *const *h_renders, const uint8_t 
         const int rc = enqueue_grid(ctx, h_renders[off], m, 0, m, h_warps[off], 1, ctx->d_pair_scores + off, nullptr, false, nullptr,
                                     nullptr, nullptr, nullptr);
         ctx->pair_renders = ctx->pair_warps = nullptr;
-        if (rc != NMI_OK) return rc;
-        if (!ctx->last_parts) return NMI_ERR_UNSUPPORTED;  // cannot happen: m * 2 <= compute units
+        if (rc != NMI_OK) return rc;  // (NMI_ERR_UNSUPPORTED, before any launch, had no split form fitted after all)
+        if (!n_launches++) first_epoch = ctx->last_epoch;
     }
     NMI_HIP_TRY(ctx, hipMemcpyAsync(h_scores, ctx->d_pair_scores, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (split_timed_out(ctx)) {  // now one pair at a time
+    bool failed = false;  // every launch of the batch answers for itself (epochs are consecutive, apart from the skipped multiples of 65536)
+    for (uint32_t e = first_epoch; n_launches && e - first_epoch <= ctx->last_epoch - first_epoch; ++e)
+        failed = split_launch_failed(ctx, ctx->last_parts, e) || failed;
+    if (failed) {  // now one pair at a time, through nmi_grid_kernel
         const int rc = nmi_eval_pairs(ctx, h_renders, h_warps, n, h_scores);
         if (rc == NMI_OK) ctx->detail = kSplitTimeoutNote;
         return rc;

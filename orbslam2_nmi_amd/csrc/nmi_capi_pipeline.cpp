@@ -19,7 +19,8 @@ extern "C" {
 
 struct nmi_level {
     nmi_ctx *ctx = nullptr;
-    int S = 0, Wn = 0, size = 1;
+    int S = 0, Wn = 0, size = 1;                // this rank's block: S views x Wn warps ...
+    int s_offset = 0, S_total = 0, w_offset = 0, Wn_total = 0;  // ... of an S_total x Wn_total level (block == level on one rank)
     uint8_t *d_renders = nullptr, *d_warps = nullptr;
     uint32_t *d_zbuf = nullptr;
     float *d_mvps = nullptr, *h_mvps = nullptr, *d_coeffs = nullptr, *h_coeffs = nullptr;
@@ -59,12 +60,21 @@ int nmi_level_destroy(nmi_level *lv)
 
 // Common part of nmi_level_create (tex == nullptr: coloured points, d_attr = red) and nmi_level_create_mesh (tex: textured
 // triangles, d_attr = uv, n = triangles).
+struct LevelBlock {
+    int32_t S, s_offset, S_total, Wn, w_offset, Wn_total;
+};
+
 static int level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_attr, int64_t n_points, const nmi_texture *tex,
-                        const uint8_t *d_frame, int32_t S, int32_t Wn, float point_size, nmi_level **out)
+                        const uint8_t *d_frame, const LevelBlock &blk, float point_size, nmi_level **out)
 {
     const float *d_red = d_attr;
-    if (!ctx || !out || !d_frame || S <= 0 || Wn <= 0 || n_points < 0 || (n_points > 0 && (!d_xyz || !d_attr)))
+    const int32_t S = blk.S, Wn = blk.Wn;
+    if (!ctx || !out || !d_frame || S < 0 || Wn < 0 || n_points < 0 || (n_points > 0 && (!d_xyz || !d_attr)))
         return NMI_ERR_INVALID_ARGUMENT;
+    if (blk.S_total <= 0 || blk.Wn_total <= 0 || blk.s_offset < 0 || blk.w_offset < 0 || blk.s_offset + S > blk.S_total ||
+        blk.w_offset + Wn > blk.Wn_total)
+        return NMI_ERR_INVALID_ARGUMENT;
+    if ((int64_t)blk.S_total * blk.Wn_total >= 0x7FFFFFFFll) return NMI_ERR_UNSUPPORTED;  // index lives in 32 bits of the key
     if (tex && tex->ctx != ctx) return NMI_ERR_INVALID_ARGUMENT;
     if (!ctx->params.use_bg) return NMI_ERR_UNSUPPORTED;
     *out = nullptr;
@@ -79,6 +89,23 @@ static int level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_attr, i
     lv->ctx = ctx;
     lv->S = S;
     lv->Wn = Wn;
+    lv->s_offset = blk.s_offset;
+    lv->S_total = blk.S_total;
+    lv->w_offset = blk.w_offset;
+    lv->Wn_total = blk.Wn_total;
+    if (S == 0 || Wn == 0) {
+        // An empty block (more ranks than cells on the sharded axis): nothing to render, warp or score.  The rank still owns
+        // a key word -- "no candidate" -- for the level's collective (nmi_level_run_rccl).
+        hipError_t e0 = hipMalloc((void **)&lv->d_key, sizeof(unsigned long long));
+        if (e0 == hipSuccess) e0 = hipMemset(lv->d_key, 0, sizeof(unsigned long long));
+        if (e0 != hipSuccess) {
+            const int rc = hip_fail(ctx, e0, "nmi_level_create (empty block)");
+            nmi_level_destroy(lv);
+            return rc;
+        }
+        *out = lv;
+        return NMI_OK;
+    }
     int size = (int)floorf(point_size + 0.5f);
     lv->size = size < 1 ? 1 : (size > 64 ? 64 : size);
     const nmi_params &p = ctx->params;
@@ -124,8 +151,9 @@ static int level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_attr, i
     a.warp_stack = lv->d_warps;
     a.S_local = S;
     a.Wn = Wn;
-    a.s_offset = 0;
-    a.S_total = S;
+    a.s_offset = blk.s_offset;  // global indices in the key (commit_score): the winner of a block is a cell of the whole level
+    a.S_total = blk.S_total;
+    a.w_offset = blk.w_offset;
     nmi::set_geometry(a, p.width, p.height, lv->d_renders, lv->d_warps, p.render_bottom_up != 0);
     a.shift = ctx->shift;
     a.mode = p.mode;
@@ -184,23 +212,40 @@ extern "C" {
 int nmi_level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int64_t n_points, const uint8_t *d_frame, int32_t S,
                      int32_t Wn, float point_size, nmi_level **out)
 {
-    return level_create(ctx, d_xyz, d_red, n_points, nullptr, d_frame, S, Wn, point_size, out);
+    if (S <= 0 || Wn <= 0) return NMI_ERR_INVALID_ARGUMENT;
+    return level_create(ctx, d_xyz, d_red, n_points, nullptr, d_frame, LevelBlock{S, 0, S, Wn, 0, Wn}, point_size, out);
 }
 
 int nmi_level_create_mesh(nmi_ctx *ctx, const float *d_xyz, const float *d_uv, int64_t n_triangles, const nmi_texture *tex,
                           const uint8_t *d_frame, int32_t S, int32_t Wn, nmi_level **out)
 {
-    if (!tex) return NMI_ERR_INVALID_ARGUMENT;
-    return level_create(ctx, d_xyz, d_uv, n_triangles, tex, d_frame, S, Wn, 1.0f, out);
+    if (!tex || S <= 0 || Wn <= 0) return NMI_ERR_INVALID_ARGUMENT;
+    return level_create(ctx, d_xyz, d_uv, n_triangles, tex, d_frame, LevelBlock{S, 0, S, Wn, 0, Wn}, 1.0f, out);
 }
 
-int nmi_level_run(nmi_level *lv, const float *h_mvps, const double *h_forward, int64_t *h_best_index, float *h_best_score)
+int nmi_level_create_block(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int64_t n_points, const uint8_t *d_frame, int32_t S_local,
+                           int32_t s_offset, int32_t S_total, int32_t Wn_local, int32_t w_offset, int32_t Wn_total, float point_size,
+                           nmi_level **out)
 {
-    if (!lv || !h_mvps || !h_forward) return NMI_ERR_INVALID_ARGUMENT;
+    return level_create(ctx, d_xyz, d_red, n_points, nullptr, d_frame, LevelBlock{S_local, s_offset, S_total, Wn_local, w_offset, Wn_total},
+                        point_size, out);
+}
+
+int nmi_level_create_mesh_block(nmi_ctx *ctx, const float *d_xyz, const float *d_uv, int64_t n_triangles, const nmi_texture *tex,
+                                const uint8_t *d_frame, int32_t S_local, int32_t s_offset, int32_t S_total, int32_t Wn_local,
+                                int32_t w_offset, int32_t Wn_total, nmi_level **out)
+{
+    if (!tex) return NMI_ERR_INVALID_ARGUMENT;
+    return level_create(ctx, d_xyz, d_uv, n_triangles, tex, d_frame, LevelBlock{S_local, s_offset, S_total, Wn_local, w_offset, Wn_total},
+                        1.0f, out);
+}
+
+}  // extern "C"
+
+// Parameters of this replay into the pinned buffers the graph's first node reads; then the launch.  No waiting.
+static int level_launch(nmi_level *lv, const float *h_mvps, const double *h_forward)
+{
     nmi_ctx *ctx = lv->ctx;
-    ctx->detail.clear();
-    DeviceGuard guard(ctx->device);
-    // the previous replay has completed (this call is blocking), so the pinned parameter buffers are free to rewrite
     memcpy(lv->h_mvps, h_mvps, (size_t)lv->S * 16 * sizeof(float));
     for (int w = 0; w < lv->Wn; ++w) {
         const double *m = h_forward + (size_t)w * 9;
@@ -211,11 +256,42 @@ int nmi_level_run(nmi_level *lv, const float *h_mvps, const double *h_forward, i
                                (m[3] * m[7] - m[4] * m[6]) / det, (m[1] * m[6] - m[0] * m[7]) / det, (m[0] * m[4] - m[1] * m[3]) / det};
         for (int k = 0; k < 9; ++k) lv->h_coeffs[w * 9 + k] = (float)inv[k];
     }
-    // The search kernel's last workgroup stores the winner (never all ones: scores are non-negative floats) into
-    // *h_key with system scope; polling that word returns ~10 us earlier than waiting for the stream to drain.
     constexpr unsigned long long kPending = ~0ull;
     __atomic_store_n(lv->h_key, kPending, __ATOMIC_RELEASE);
     NMI_HIP_TRY(ctx, hipGraphLaunch(lv->exec, ctx->stream));
+    return NMI_OK;
+}
+
+// nmi_level_run_rccl's device side (nmi_capi_rccl.cpp): replay the block's graph (if the block is not empty) and hand back the
+// device word that holds this rank's key once the context's stream has reached this point.
+int nmi_internal::level_enqueue(nmi_level *lv, const float *h_mvps, const double *h_forward, const unsigned long long **d_key)
+{
+    if (!lv || !d_key) return NMI_ERR_INVALID_ARGUMENT;
+    *d_key = lv->d_key;
+    if (lv->S == 0 || lv->Wn == 0) return NMI_OK;  // d_key holds 0 = "no candidate" since creation
+    if (!h_mvps || !h_forward) return NMI_ERR_INVALID_ARGUMENT;
+    lv->ctx->detail.clear();
+    return level_launch(lv, h_mvps, h_forward);
+}
+
+nmi_ctx *nmi_internal::level_ctx(nmi_level *lv) { return lv ? lv->ctx : nullptr; }
+
+extern "C" {
+
+int nmi_level_run(nmi_level *lv, const float *h_mvps, const double *h_forward, int64_t *h_best_index, float *h_best_score)
+{
+    if (!lv) return NMI_ERR_INVALID_ARGUMENT;
+    if (lv->S == 0 || lv->Wn == 0) return nmi_key_unpack(0, h_best_index, h_best_score);  // empty block: no candidate
+    if (!h_mvps || !h_forward) return NMI_ERR_INVALID_ARGUMENT;
+    nmi_ctx *ctx = lv->ctx;
+    ctx->detail.clear();
+    DeviceGuard guard(ctx->device);
+    // the previous replay has completed (this call is blocking), so the pinned parameter buffers are free to rewrite.
+    // The search kernel's last workgroup stores the winner (never all ones: scores are non-negative floats) into
+    // *h_key with system scope; polling that word returns ~10 us earlier than waiting for the stream to drain.
+    constexpr unsigned long long kPending = ~0ull;
+    const int lrc = level_launch(lv, h_mvps, h_forward);
+    if (lrc != NMI_OK) return lrc;
     unsigned long long key = kPending;
     for (uint64_t spin = 0; key == kPending; ++spin) {
         key = __atomic_load_n(lv->h_key, __ATOMIC_ACQUIRE);
@@ -236,6 +312,7 @@ int nmi_level_copy_outputs(nmi_level *lv, uint8_t *h_renders, uint8_t *h_warps, 
 {
     if (!lv) return NMI_ERR_INVALID_ARGUMENT;
     nmi_ctx *ctx = lv->ctx;
+    if (lv->S == 0 || lv->Wn == 0) return NMI_OK;  // empty block: nothing was produced
     DeviceGuard guard(ctx->device);
     NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // nmi_level_run returns when the winner is posted, a little before the graph has drained
     const size_t npix = (size_t)ctx->npix;
@@ -258,17 +335,24 @@ struct nmi_stream {
         uint8_t *d_renders = nullptr;
         float *d_ratings = nullptr;  // [max_Wn][max_S], only with nmi_stream_keep_ratings
         int S = 0, Wn = 0;           // grid of the slot's latest submission
-        unsigned long long *d_key = nullptr;
+        unsigned long long *d_key = nullptr;      // [2]: this rank's key, and the all-reduced one (block submissions with a communicator)
         unsigned long long *h_key = nullptr;
         hipEvent_t copied = nullptr, done = nullptr;
         int64_t ticket = -1;
         bool waited = true;
+        bool failed = false;         // its search timed out in the split kernel and could not be redone (nmi_stream_wait)
+        int parts = 0;               // split form of the slot's launch (0: nmi_grid_kernel) and its epoch: the launch answers
+        uint32_t epoch = 0;          //   for itself when the ticket is waited for, whatever was launched after it
+        int s_offset = 0, S_total = 0, w_offset = 0;  // position of the slot's block in its level
+        int warp_buf = 0;            // warp buffer the search read, and that buffer's generation at submission
+        uint64_t warp_gen = 0;
     };
     Slot *slots = nullptr;
     uint8_t *d_frame[2] = {nullptr, nullptr};  // frames alternate so an upload never overwrites one still being warped
     uint8_t *d_warps[2] = {nullptr, nullptr};
     hipEvent_t frame_copied = nullptr, warps_free[2] = {nullptr, nullptr};
     int warp_buf = 0;      // buffer holding the current warp stack
+    uint64_t warp_gen[2] = {0, 0};  // refills of each warp buffer so far
     int cur_Wn = 0;
     bool have_warps = false;
     bool keep_ratings = false;
@@ -326,7 +410,7 @@ int nmi_stream_create(nmi_ctx *ctx, int32_t max_S, int32_t max_Wn, int32_t depth
     for (int i = 0; st->slots && i < depth && e == hipSuccess; ++i) {
         nmi_stream::Slot &s = st->slots[i];
         ok(hipMalloc((void **)&s.d_renders, npix * max_S));
-        ok(hipMalloc((void **)&s.d_key, sizeof(unsigned long long)));
+        ok(hipMalloc((void **)&s.d_key, 2 * sizeof(unsigned long long)));
         ok(hipHostMalloc((void **)&s.h_key, sizeof(unsigned long long), hipHostMallocDefault));
         ok(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
         ok(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
@@ -349,9 +433,20 @@ int nmi_stream_create(nmi_ctx *ctx, int32_t max_S, int32_t max_Wn, int32_t depth
 int nmi_stream_submit(nmi_stream *st, const uint8_t *h_render_stack, int32_t S, const uint8_t *h_frame,
                       const double *h_forward, int32_t Wn, int64_t *ticket)
 {
-    if (!st || !h_render_stack || !ticket || S <= 0 || S > st->max_S) return NMI_ERR_INVALID_ARGUMENT;
+    if (S <= 0) return NMI_ERR_INVALID_ARGUMENT;
+    return nmi_stream_submit_block(st, h_render_stack, S, 0, S, h_frame, h_forward, Wn, 0, h_frame ? Wn : (st ? st->cur_Wn : 0), nullptr, ticket);
+}
+
+int nmi_stream_submit_block(nmi_stream *st, const uint8_t *h_render_stack, int32_t S, int32_t s_offset, int32_t S_total,
+                            const uint8_t *h_frame, const double *h_forward, int32_t Wn, int32_t w_offset, int32_t Wn_total,
+                            void *nccl_comm, int64_t *ticket)
+{
+    if (!st || !ticket || S < 0 || S > st->max_S || (S > 0 && !h_render_stack)) return NMI_ERR_INVALID_ARGUMENT;
     if (h_frame && (!h_forward || Wn <= 0 || Wn > st->max_Wn)) return NMI_ERR_INVALID_ARGUMENT;
-    if (!h_frame && !st->have_warps) return NMI_ERR_INVALID_ARGUMENT;
+    if (!h_frame && !st->have_warps && !(S == 0 && nccl_comm)) return NMI_ERR_INVALID_ARGUMENT;
+    const int32_t Wn_block = h_frame ? Wn : st->cur_Wn;
+    if (s_offset < 0 || w_offset < 0 || s_offset + S > S_total || w_offset + Wn_block > Wn_total) return NMI_ERR_INVALID_ARGUMENT;
+    if ((int64_t)S_total * Wn_total >= 0x7FFFFFFFll) return NMI_ERR_UNSUPPORTED;
     nmi_ctx *ctx = st->ctx;
     ctx->detail.clear();
     DeviceGuard guard(ctx->device);
@@ -361,7 +456,7 @@ int nmi_stream_submit(nmi_stream *st, const uint8_t *h_render_stack, int32_t S, 
     const size_t npix = (size_t)ctx->npix;
 
     // copy stream: render stack of this level into the slot (the slot's previous search finished: it was waited for)
-    NMI_HIP_TRY(ctx, hipMemcpyAsync(s.d_renders, h_render_stack, npix * S, hipMemcpyHostToDevice, st->copy));
+    if (S > 0) NMI_HIP_TRY(ctx, hipMemcpyAsync(s.d_renders, h_render_stack, npix * S, hipMemcpyHostToDevice, st->copy));
     if (h_frame) {
         const int nb = st->have_warps ? st->warp_buf ^ 1 : 0;
         // the buffer being refilled was last read by searches submitted before the previous frame switch
@@ -373,6 +468,7 @@ int nmi_stream_submit(nmi_stream *st, const uint8_t *h_render_stack, int32_t S, 
         int rc = nmi_warp_stack(ctx, st->d_frame[nb], h_forward, Wn, st->d_warps[nb]);
         if (rc != NMI_OK) return rc;
         st->warp_buf = nb;
+        ++st->warp_gen[nb];
         st->cur_Wn = Wn;
         st->have_warps = true;
     }
@@ -384,13 +480,32 @@ int nmi_stream_submit(nmi_stream *st, const uint8_t *h_render_stack, int32_t S, 
         NMI_HIP_TRY(ctx, hipMalloc((void **)&s.d_ratings, (size_t)st->max_S * st->max_Wn * sizeof(float)));
     s.S = S;
     s.Wn = st->cur_Wn;
-    int rc = enqueue_grid(ctx, s.d_renders, S, 0, S, st->d_warps[st->warp_buf], st->cur_Wn, st->keep_ratings ? s.d_ratings : nullptr,
-                          s.d_key, false, nullptr, nullptr, nullptr, nullptr);
+    // nmi_stream_wait checks this very launch for a split-kernel timeout (parts, epoch below) and redoes it -- which it cannot do
+    // once the key has gone into a collective, so submissions with a communicator keep to the one-workgroup kernel
+    ctx->allow_unchecked_split = nccl_comm == nullptr;
+    s.s_offset = s_offset;
+    s.S_total = S_total;
+    s.w_offset = w_offset;
+    int rc = enqueue_grid(ctx, s.d_renders, S, s_offset, S_total, st->d_warps[st->warp_buf], st->cur_Wn, st->keep_ratings ? s.d_ratings : nullptr,
+                          s.d_key, false, nullptr, nullptr, nullptr, nullptr, w_offset);
+    ctx->allow_unchecked_split = false;
     if (rc != NMI_OK) return rc;
-    NMI_HIP_TRY(ctx, hipMemcpyAsync(s.h_key, s.d_key, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    s.parts = ctx->last_parts;
+    s.epoch = ctx->last_epoch;
+    s.warp_buf = st->warp_buf;
+    s.warp_gen = st->warp_gen[st->warp_buf];
+    const unsigned long long *result = s.d_key;
+    if (nccl_comm) {
+        // the level's only exchange: 8-byte MAX all-reduce of the packed keys, issued in submission order on every rank
+        rc = rccl_allreduce_key(ctx, s.d_key, s.d_key + 1, nccl_comm);
+        if (rc != NMI_OK) return rc;
+        result = s.d_key + 1;
+    }
+    NMI_HIP_TRY(ctx, hipMemcpyAsync(s.h_key, result, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     NMI_HIP_TRY(ctx, hipEventRecord(s.done, ctx->stream));
     s.ticket = t;
     s.waited = false;
+    s.failed = false;
     *ticket = t;
     ++st->next_ticket;
     return NMI_OK;
@@ -408,7 +523,7 @@ int nmi_stream_copy_ratings(nmi_stream *st, int64_t ticket, float *h_ratings, in
     if (!st || !h_ratings || ticket < 0 || ticket >= st->next_ticket) return NMI_ERR_INVALID_ARGUMENT;
     nmi_stream::Slot &s = st->slots[ticket % st->depth];
     // valid from nmi_stream_wait(ticket) until the slot is submitted to again
-    if (s.ticket != ticket || !s.waited || !s.d_ratings || n != (int64_t)s.S * s.Wn) return NMI_ERR_INVALID_ARGUMENT;
+    if (s.ticket != ticket || !s.waited || s.failed || !s.d_ratings || n != (int64_t)s.S * s.Wn) return NMI_ERR_INVALID_ARGUMENT;
     nmi_ctx *ctx = st->ctx;
     DeviceGuard guard(ctx->device);
     NMI_HIP_TRY(ctx, hipMemcpy(h_ratings, s.d_ratings, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
@@ -424,7 +539,27 @@ int nmi_stream_wait(nmi_stream *st, int64_t ticket, int64_t *h_best_index, float
     DeviceGuard guard(ctx->device);
     NMI_HIP_TRY(ctx, hipEventSynchronize(s.done));
     s.waited = true;
-    if (split_timed_out(ctx)) return NMI_ERR_NOT_READY;  // resubmit: the split forms are off from here on
+    if (split_launch_failed(ctx, s.parts, s.epoch)) {
+        // This ticket's search (a small grid on the split kernel) timed out in a hand-off.  Its render stack is still in the
+        // slot; if its warp stack is too (no later frame has refilled that buffer) the search is redone here, behind
+        // whatever was submitted since, by nmi_grid_kernel (the split forms are paused now).  Otherwise the ticket fails:
+        // NMI_ERR_NOT_READY, its rating table is withheld, and the caller submits the level again.
+        if (st->warp_gen[s.warp_buf] != s.warp_gen) {
+            s.failed = true;
+            ctx->detail = "split kernel hand-off timed out and the ticket's warp stack is gone: submit the level again";
+            return NMI_ERR_NOT_READY;
+        }
+        const int rc = enqueue_grid(ctx, s.d_renders, s.S, s.s_offset, s.S_total, st->d_warps[s.warp_buf], s.Wn,
+                                    st->keep_ratings ? s.d_ratings : nullptr, s.d_key, false, nullptr, nullptr, nullptr, nullptr, s.w_offset);
+        if (rc != NMI_OK) {
+            s.failed = true;
+            return rc;
+        }
+        s.parts = 0;
+        NMI_HIP_TRY(ctx, hipMemcpyAsync(s.h_key, s.d_key, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->detail = "split kernel hand-off timed out; ticket redone by the one-workgroup kernel, split forms paused (nmi_split_status)";
+    }
     return nmi_key_unpack(*s.h_key, h_best_index, h_best_score);
 }
 

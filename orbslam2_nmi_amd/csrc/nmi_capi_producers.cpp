@@ -11,14 +11,18 @@ namespace nmi_internal {
 // of textured facades.
 int ensure_tile_queue(nmi_ctx *ctx)
 {
-    if (ctx->d_tile_queue) return NMI_OK;
-    constexpr unsigned long long kItems = 4ull << 20;
-    NMI_HIP_TRY(ctx, hipMalloc(&ctx->d_tile_queue, (size_t)kItems * nmi::mesh_tile_item_bytes()));
-    ctx->tile_queue_cap = kItems;
-    NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tile_state, 4 * sizeof(unsigned long long)));
-    constexpr unsigned long long kClipItems = 1ull << 18;  // (triangle, view) pairs crossing the near plane; beyond it: rescan
-    NMI_HIP_TRY(ctx, hipMalloc(&ctx->d_clip_queue, (size_t)kClipItems * nmi::mesh_clip_item_bytes()));
-    ctx->clip_queue_cap = kClipItems;
+    // each of the three allocations is made when missing: a failure half-way must not leave a context that skips the rest for good
+    if (!ctx->d_tile_queue) {
+        constexpr unsigned long long kItems = 4ull << 20;
+        NMI_HIP_TRY(ctx, hipMalloc(&ctx->d_tile_queue, (size_t)kItems * nmi::mesh_tile_item_bytes()));
+        ctx->tile_queue_cap = kItems;
+    }
+    if (!ctx->d_tile_state) NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tile_state, 4 * sizeof(unsigned long long)));
+    if (!ctx->d_clip_queue) {
+        constexpr unsigned long long kClipItems = 1ull << 18;  // (triangle, view) pairs crossing the near plane; beyond it: rescan
+        NMI_HIP_TRY(ctx, hipMalloc(&ctx->d_clip_queue, (size_t)kClipItems * nmi::mesh_clip_item_bytes()));
+        ctx->clip_queue_cap = kClipItems;
+    }
     return NMI_OK;
 }
 

@@ -60,6 +60,14 @@ int rccl_fail(nmi_ctx *ctx, int r, const char *what)
 }
 }  // namespace
 
+int nmi_internal::rccl_allreduce_key(nmi_ctx *ctx, const unsigned long long *d_send, unsigned long long *d_recv, void *nccl_comm)
+{
+    if (!nccl_comm) return NMI_ERR_INVALID_ARGUMENT;
+    if (!rccl().ok) return NMI_ERR_UNSUPPORTED;
+    const int r = rccl().all_reduce(d_send, d_recv, 1, kNcclUint64, kNcclMax, nccl_comm, ctx->stream);
+    return r == 0 ? NMI_OK : rccl_fail(ctx, r, "ncclAllReduce");
+}
+
 extern "C" {
 
 int nmi_rccl_unique_id(uint8_t out_id[128])
@@ -101,18 +109,18 @@ int nmi_search_grid_block_rccl(nmi_ctx *ctx, const uint8_t *render_stack, int32_
 {
     if (!nccl_comm) return NMI_ERR_INVALID_ARGUMENT;
     if (!rccl().ok) return NMI_ERR_UNSUPPORTED;
-    int rc = nmi_search_grid_block(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn_local, w_offset, Wn_total, d_ratings,
-                                   nullptr, nullptr);
+    int rc = search_block(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn_local, w_offset, Wn_total, d_ratings, nullptr, nullptr,
+                          /*caller_checks=*/true);
     if (rc != NMI_OK) return rc;
     DeviceGuard guard(ctx->device);
     if (ctx->last_parts) {
         // A small block went to the split kernel, whose hand-offs can time out (nmi_split_kernel.hip).  Every rank must
         // issue exactly one collective with a valid key, so this rank settles its own search first: wait, and on a
-        // timeout redo it with the one-workgroup kernel (the split forms are then off for this context).
+        // timeout redo it with the one-workgroup kernel (the split forms are paused for a while, nmi_split_status).
         NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (split_timed_out(ctx)) {
-            rc = nmi_search_grid_block(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn_local, w_offset, Wn_total, d_ratings,
-                                       nullptr, nullptr);
+            rc = search_block(ctx, render_stack, S_local, s_offset, S_total, warp_stack, Wn_local, w_offset, Wn_total, d_ratings, nullptr,
+                              nullptr, true);
             if (rc != NMI_OK) return rc;
         }
     }
@@ -120,8 +128,28 @@ int nmi_search_grid_block_rccl(nmi_ctx *ctx, const uint8_t *render_stack, int32_
     // buffer is this launch's key slot (zero for a rank whose block is empty), the receive buffer a word of its own, so
     // the global winner never lands in a ping-pong slot that a later launch expects to find zero.
     const unsigned long long *send = ctx->d_keys + ctx->last_slot;
-    int r = rccl().all_reduce(send, ctx->d_reduced_key, 1, kNcclUint64, kNcclMax, nccl_comm, ctx->stream);
-    if (r != 0) return rccl_fail(ctx, r, "ncclAllReduce");
+    rc = rccl_allreduce_key(ctx, send, ctx->d_reduced_key, nccl_comm);
+    if (rc != NMI_OK) return rc;
+    NMI_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_key, ctx->d_reduced_key, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return nmi_key_unpack(*ctx->h_key, h_best_index, h_best_score);
+}
+
+// One search level sharded over the ranks of `nccl_comm` (the latency form of BASELINE.json configs[4]): this
+// rank's block of the level -- its views rendered, its warps made, its cells scored by one graph replay -- then the level's
+// only exchange, the 8-byte MAX all-reduce of the packed key on the context's stream, and the winner on every rank.
+int nmi_level_run_rccl(nmi_level *lv, const float *h_mvps, const double *h_forward, void *nccl_comm, int64_t *h_best_index,
+                       float *h_best_score)
+{
+    nmi_ctx *ctx = level_ctx(lv);
+    if (!ctx || !nccl_comm) return NMI_ERR_INVALID_ARGUMENT;
+    if (!rccl().ok) return NMI_ERR_UNSUPPORTED;
+    DeviceGuard guard(ctx->device);
+    const unsigned long long *send = nullptr;
+    int rc = level_enqueue(lv, h_mvps, h_forward, &send);
+    if (rc != NMI_OK) return rc;
+    rc = rccl_allreduce_key(ctx, send, ctx->d_reduced_key, nccl_comm);
+    if (rc != NMI_OK) return rc;
     NMI_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_key, ctx->d_reduced_key, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return nmi_key_unpack(*ctx->h_key, h_best_index, h_best_score);

@@ -42,6 +42,16 @@ struct nmi_ctx {
     int slot = 0;                          // key slot of the next launch
     int last_slot = 0;                     // key slot of the most recent launch
     int last_parts = 0;                    // parts per candidate of the most recent launch (0 = one workgroup per candidate)
+    uint32_t last_epoch = 0;               // its split epoch (meaningful when last_parts != 0)
+    // Split-kernel liveness (nmi_split_kernel.hip: its consumers spin, so a launch whose workgroups are not all resident
+    // times out after 2 ms).  A timeout is attributed to ITS launch (epoch), that search is redone by nmi_grid_kernel, and the
+    // split forms stay off for split_cooldown further small-grid launches -- 16, doubling per consecutive timeout up to
+    // 4096 -- after which they are tried again; a split launch that is checked and found good re-arms the short cooldown.
+    bool allow_unchecked_split = false;    // this launch's caller checks for a timeout itself (blocking calls, stream, RCCL)
+    uint32_t split_timeouts = 0;           // timeouts seen so far
+    uint32_t split_cooldown = 0;           // small-grid launches still to go through nmi_grid_kernel
+    uint32_t split_backoff = kSplitBackoffMin;  // cooldown the next timeout starts
+    static constexpr uint32_t kSplitBackoffMin = 16, kSplitBackoffMax = 4096;
     int result_path = 1;                   // 1 mailbox spin (default), 0 hipMemcpyAsync + stream sync
     bool posted = false;                   // the most recent launch posts to the mailbox
     float *d_pair_rating = nullptr;
@@ -65,7 +75,7 @@ struct nmi_ctx {
     int slab_cap = 0;
     unsigned long long *d_blocks = nullptr;  // counter blocks (granules) of the split kernel's pixel parts
     uint32_t split_epoch = 0;             // tag of the latest split launch
-    uint32_t *h_split_error = nullptr, *d_split_error = nullptr;  // pinned: raised by the kernel when a hand-off timed out
+    uint32_t *h_split_error = nullptr, *d_split_error = nullptr;  // pinned ring [16]: word (epoch & 15) = epoch of a launch whose hand-off timed out
     size_t blocks_bytes = 0;
     // nmi_eval_pairs: pointer tables [2][pairs_cap] in pinned host memory (renders, then warps) + device scores
     const uint8_t **h_pair_table = nullptr, **d_pair_table = nullptr;
@@ -133,6 +143,10 @@ struct nmi_texture {
 namespace nmi_internal {
 
 int ensure_tile_queue(nmi_ctx *ctx);
+int level_enqueue(nmi_level *lv, const float *h_mvps, const double *h_forward, const unsigned long long **d_key);
+nmi_ctx *level_ctx(nmi_level *lv);
+// ncclAllReduce(ncclMax, ncclUint64) of one 8-byte key on the context's stream, out of place (nmi_capi_rccl.cpp)
+int rccl_allreduce_key(nmi_ctx *ctx, const unsigned long long *d_send, unsigned long long *d_recv, void *nccl_comm);
 
 int hip_fail(nmi_ctx *ctx, hipError_t e, const char *what);
 void build_order(int S, int Wn, int *order);
@@ -144,7 +158,13 @@ int wait_word(nmi_ctx *ctx, const volatile unsigned long long *word, unsigned lo
               unsigned long long *out);
 int stage_floats(nmi_ctx *ctx, StagingRing &ring, const float *h_src, size_t n, float **d_out);
 int fetch_key(nmi_ctx *ctx, unsigned long long *key);
-bool split_timed_out(nmi_ctx *ctx);
+bool split_timed_out(nmi_ctx *ctx);                                     // ... the most recent launch
+bool split_launch_failed(nmi_ctx *ctx, int parts, uint32_t epoch);      // ... the launch with this epoch (waits for the stream on a hit)
+// nmi_search_grid_block without the argument checks; caller_checks: the caller looks for a split timeout itself, so small
+// grids may use the split kernel although the call only enqueues (h_key == nullptr)
+int search_block(nmi_ctx *ctx, const uint8_t *render_stack, int32_t S_local, int32_t s_offset, int32_t S_total, const uint8_t *warp_stack,
+                 int32_t Wn_local, int32_t w_offset, int32_t Wn_total, float *d_ratings, uint64_t *d_key, uint64_t *h_key,
+                 bool caller_checks);
 int check_grid_args(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_offset, int S_total, const uint8_t *warp_stack,
                     int Wn);
 

@@ -67,7 +67,7 @@ struct GridArgs {
     struct SplitSlab *slabs;        // split kernel: one hand-off slab per candidate (see nmi_split_kernel.hip)
     unsigned long long *blocks;     // split kernel with pixel parts: [candidate][row part][pixel part] blocks of 24+24+16-bit granules
     uint32_t epoch;                 // split kernel: this launch's tag (never 0; its low 16 bits never 0)
-    uint32_t *split_error;          // pinned host word, set to 1 if a hand-off of the split kernel timed out
+    uint32_t *split_error;          // pinned host words [16]: a launch whose hand-off timed out stores its epoch into word epoch & 15
     unsigned long long *dbg_stamps; // tools only (NMI_OPT_STAMPS): [workgroup][8] wall_clock64 stamps at phase boundaries
     uint32_t *dbg_joint, *dbg_h1, *dbg_h2;
     float *dbg_sums;

@@ -33,7 +33,8 @@
 // form of this kernel's first version: 5 us for the pixel-part merge, 16 us per pair; now 2 us and 11 us).
 // The consumers spin, so every workgroup of the launch must be able to run at once: the host launches this kernel only
 // with one unit per workgroup and no more workgroups than compute units (one per CU: LDS padded), and every poll loop is
-// bounded -- on a timeout the kernel raises GridArgs::split_error and the host redoes the call with nmi_grid_kernel.
+// bounded (2 ms) -- on a timeout the kernel posts its epoch to GridArgs::split_error and the host redoes that launch's
+// search with nmi_grid_kernel, keeps the split forms off for a number of calls, then tries them again (nmi_capi.cpp).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -85,10 +86,30 @@ __device__ __forceinline__ unsigned long long load_granule(const unsigned long l
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_load_dwordx2 sc1
 }
 __device__ __forceinline__ unsigned long long granule32(uint32_t payload, uint32_t epoch) { return (unsigned long long)payload | ((unsigned long long)epoch << 32); }
-constexpr int kMaxPolls = 1 << 15;  // x (load round trip + sleep) >= 30 ms: far beyond any legitimate wait, then give up
+// Every poll loop is bounded in real time: a legitimate hand-off arrives within ~5 us; after kTimeoutTicks of the 100 MHz
+// wall clock (2 ms) the waiter gives up.  (The clock is read every 16th unsuccessful poll only; kMaxPolls is the backstop
+// should the clock misbehave.)  The timeout is reported per launch: the launch's epoch goes into word (epoch & 15) of the
+// pinned error ring, so the host can tell WHICH of several launches in flight failed (nmi_capi.cpp, split_launch_failed).
+constexpr unsigned long long kTimeoutTicks = 200000ull;
+constexpr int kMaxPolls = 1 << 15;
+struct PollGuard {
+    unsigned long long t0 = 0;
+    int tries = 0;
+    __device__ __forceinline__ bool expired()
+    {
+        if (++tries >= kMaxPolls) return true;
+        if ((tries & 15) != 1) return false;
+        const unsigned long long now = wall_clock64();
+        if (tries == 1) {
+            t0 = now;
+            return false;
+        }
+        return now - t0 > kTimeoutTicks;
+    }
+};
 __device__ __forceinline__ void raise_timeout(const GridArgs &a)
 {
-    if (a.split_error) __hip_atomic_store(a.split_error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.split_error) __hip_atomic_store(a.split_error + (a.epoch & 15u), a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // 16 pixels of one lane, hot case (BG on, 256 bins).  xorpat holds (part * kRows) in every byte: after r ^= xorpat a pixel
@@ -364,7 +385,7 @@ __device__ __forceinline__ void gather_slab(SplitLds<K> &lds, const GridArgs &a,
     if (tid < kBins) {
         uint32_t c = 0;
         unsigned long long v[K];
-        int tries = 0;
+        PollGuard guard;
         bool ok;
         do {
             ok = true;
@@ -373,7 +394,7 @@ __device__ __forceinline__ void gather_slab(SplitLds<K> &lds, const GridArgs &a,
 #pragma unroll
             for (int j = 0; j < K; ++j) ok = ok && (uint32_t)(v[j] >> 32) == a.epoch;
             if (!ok) __builtin_amdgcn_s_sleep(8);
-        } while (!ok && ++tries < kMaxPolls);
+        } while (!ok && !guard.expired());
         if (!ok) raise_timeout(a);
 #pragma unroll
         for (int j = 0; j < K; ++j) c += (uint32_t)v[j];
@@ -381,8 +402,8 @@ __device__ __forceinline__ void gather_slab(SplitLds<K> &lds, const GridArgs &a,
     } else if (tid < 3 * kBins) {
         const unsigned long long *src = tid < 2 * kBins ? &slab->hist_render[tid - kBins] : &slab->row_sums[tid - 2 * kBins];
         unsigned long long v;
-        int tries = 0;
-        while ((uint32_t)((v = load_granule(src)) >> 32) != a.epoch && ++tries < kMaxPolls) __builtin_amdgcn_s_sleep(8);
+        PollGuard guard;
+        while ((uint32_t)((v = load_granule(src)) >> 32) != a.epoch && !guard.expired()) __builtin_amdgcn_s_sleep(8);
         if ((uint32_t)(v >> 32) != a.epoch) raise_timeout(a);
         if (tid < 2 * kBins)
             lds.fin_render[tid - kBins] = (uint32_t)v;
@@ -474,7 +495,7 @@ __device__ __forceinline__ bool merge_pixel_parts(SplitLds<K> &lds, const GridAr
         return false;
     }
     unsigned long long v[kPer][P - 1];
-    int tries = 0;
+    PollGuard guard;
     bool ok;
     do {
         ok = true;
@@ -487,7 +508,7 @@ __device__ __forceinline__ bool merge_pixel_parts(SplitLds<K> &lds, const GridAr
 #pragma unroll
             for (int q = 1; q < P; ++q) ok = ok && (v[e][q - 1] >> 48) == (tag >> 48);
         if (!ok) __builtin_amdgcn_s_sleep(2);
-    } while (!ok && ++tries < kMaxPolls);
+    } while (!ok && !guard.expired());
     if (!ok) raise_timeout(a);
 #pragma unroll
     for (int e = 0; e < kPer; ++e) {

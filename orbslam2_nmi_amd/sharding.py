@@ -122,3 +122,45 @@ def run_keyframes(n_keyframes, levels, rank, world, process_keyframe, dist=None,
 def unpack_keyframe_results(table):
     """[n_keyframes, levels, 2] -> list over keyframes of [(index, float32 score)] per level."""
     return [[(int(i), np.array([b], np.uint32).view(np.float32)[0]) for i, b in kf] for kf in table]
+
+
+# ---- level-sharded form (the latency form of BASELINE.json configs[4]) ---------------------------------------------------
+# Keyframes of a LIVE sequence are not independent: each search is seeded from the drift accumulated since the previous NMI
+# fix (src/Tracking.cc:2001-2053, accumulated at :651-661, reset at :603-607) inside the sequential Track() (:598-616).  A live
+# level can therefore only be made faster by sharing ITS candidates: rank r renders / receives only its block of views
+# (grid_shard: render axis, or the warp axis when there are fewer views than ranks), makes its warps locally, scores its
+# cells with global indices, and the ranks exchange one packed 8-byte key per level (MAX all-reduce); every rank then
+# holds the level's winner and derives the next level from it.  The replica form above answers "how fast is a RECORDED
+# sequence processed", this one "how long does one live level take".
+
+def sharded_level(run_block, s_total, wn_total, rank, world, dist=None, device="cpu", group=None):
+    """One level over `world` ranks.  run_block(s_offset, s_count, w_offset, w_count) scores this rank's block and returns
+    (global linear index, score) of its winner, (-1, 0) for none; it is not called for an empty block.  The keys are
+    MAX-all-reduced through torch.distributed (`dist`; None = single rank).  -> (index, score) of the level's winner.
+    (With RCCL the product does the same inside nmi_level_run_rccl / nmi_stream_submit_block; this is the form for callers
+    that own the collective, and the one the CPU tests drive with the oracle as the scorer.)"""
+    import torch
+    so, sc, wo, wc = grid_shard(s_total, wn_total, rank, world)
+    idx, score = run_block(so, sc, wo, wc) if sc and wc else (-1, 0.0)
+    key = capi.key_pack(float(score), int(idx)) if idx >= 0 else 0
+    if dist is not None and world > 1:
+        t = torch.tensor([key], dtype=torch.int64, device=device)
+        allreduce_key(t, dist, group)
+        key = int(t.item())
+    return capi.key_unpack(key)
+
+
+def run_keyframes_level_sharded(n_keyframes, levels, process_level, table=None):
+    """Keyframes one after the other, every level on all ranks: process_level(kf, lvl, previous winners of this keyframe)
+    -> (index, score) of the level's winner (already reduced over the ranks, e.g. by sharded_level).  -> the same
+    [n_keyframes, levels, 2] table run_keyframes returns (no gather needed: every rank has every winner)."""
+    table = new_keyframe_table(n_keyframes, levels) if table is None else table
+    for kf in range(n_keyframes):
+        won = []
+        for lvl in range(levels):
+            idx, score = process_level(kf, lvl, won)
+            won.append((idx, score))
+            store_keyframe_result(table, kf, lvl, idx, score)
+    table = table.copy()
+    table[..., 0] -= 1
+    return table

@@ -7,6 +7,8 @@ rating and every winner is compared with ==: same fp32 operations in the referen
 the oracle's libm mode (the expression as written, log2f of this host) the north_star's 1e-5 is kept as a cross-check.
 The oracle is "parity unpinned" against the reference's CUDA kernels (no golden vectors exist there and they cannot be
 built here, oracle/nmi_oracle.c header); the analytic known answers are checked on the GPU directly as well."""
+import time
+
 import numpy as np
 import pytest
 
@@ -586,10 +588,11 @@ def test_eval_pairs_equals_single_calls(nmi):
 
 
 def test_split_hand_off_timeout_falls_back(nmi):
-    """The split kernel's scoring workgroup waits (bounded) for the other parts' granules.  If they never come -- here one
-    part is told to withhold them; in the field: fewer usable compute units than the device reports -- the kernel raises a
-    flag instead of hanging, and the host redoes the call with the one-workgroup-per-candidate kernel and keeps the split
-    forms off for that context.  Results stay the oracle's."""
+    """The split kernel's scoring workgroup waits (bounded: 2 ms) for the other parts' granules.  If they never come -- here
+    one part is told to withhold them; in the field: a neighbour holding compute units -- the kernel posts its epoch to the
+    error ring instead of hanging, and the host redoes THAT search with the one-workgroup-per-candidate kernel, pauses the
+    split forms for 16 small-grid launches (32, 64 ... when the retry times out again) and then uses them again.  Results stay
+    the oracle's throughout."""
     from oracle import binding as oc
     from orbslam2_nmi_amd import synthetic as sy
     wl = sy.workload(160, 120, 3, 2, seed=6)
@@ -598,18 +601,125 @@ def test_split_hand_off_timeout_falls_back(nmi):
         ro, io, bo = oc.search_grid(wl["render_stack"], wl["warp_stack"])
     with nmi.NmiContext(160, 120) as ctx:
         assert ctx.search_grid(rs, ws) == (io, bo)                      # split kernel (6 candidates -> 8 x 4 parts)
+        assert ctx.split_status() == {"timeouts": 0, "cooldown_calls_left": 0, "next_cooldown": 16, "last_launch_parts": 8}
         ctx.set_option(ctx.OPT_PHASE_MASK, 3 | 512)
         t = torch.zeros(2, 3, device="cuda")
-        assert ctx.search_grid(rs, ws, t) == (io, bo)                   # times out (>= 30 ms), redone without the split
+        t0 = time.perf_counter()
+        assert ctx.search_grid(rs, ws, t) == (io, bo)                   # times out, redone without the split
+        assert time.perf_counter() - t0 < 0.025                         # the guard is 2 ms, not 30
         assert (t.cpu().numpy() == ro).all()
         assert "timed out" in ctx._lib.nmi_last_error_detail(ctx._h).decode()
-        assert ctx.eval_pair(rs[1], ws[1]) == ro[1, 1]                  # the split forms are off now: no second timeout
+        st = ctx.split_status()
+        assert (st["timeouts"], st["cooldown_calls_left"], st["next_cooldown"], st["last_launch_parts"]) == (1, 15, 32, 0)
+        assert ctx.eval_pair(rs[1], ws[1]) == ro[1, 1]                  # paused: no second timeout although the switch is still on
+        assert ctx.split_status()["timeouts"] == 1 and ctx.split_status()["cooldown_calls_left"] == 14
         ctx.set_option(ctx.OPT_PHASE_MASK, 3)
+        for _ in range(14):
+            assert ctx.search_grid(rs, ws) == (io, bo)
+            assert ctx.split_status()["last_launch_parts"] == 0
+        assert ctx.search_grid(rs, ws) == (io, bo)                      # re-armed: the split form is in use again ...
+        st = ctx.split_status()
+        assert (st["timeouts"], st["cooldown_calls_left"], st["next_cooldown"], st["last_launch_parts"]) == (1, 0, 16, 8)
+        ctx.set_option(ctx.OPT_PHASE_MASK, 3 | 512)                     # ... and a retry that fails again doubles the pause
         assert ctx.search_grid(rs, ws) == (io, bo)
+        assert ctx.split_status()["cooldown_calls_left"] == 15
+        ctx.set_option(ctx.OPT_PHASE_MASK, 3)
+        for _ in range(15):
+            assert ctx.search_grid(rs, ws) == (io, bo)
+        ctx.set_option(ctx.OPT_PHASE_MASK, 3 | 512)
+        assert ctx.search_grid(rs, ws) == (io, bo)                      # (the good launches re-armed the short pause first)
+        assert ctx.split_status()["timeouts"] == 3
+        # an enqueue-only call (nobody would look for a timeout) never uses the split kernel
+        ctx.set_option(ctx.OPT_PHASE_MASK, 3)
+        for _ in range(20):
+            ctx.search_grid(rs, ws)
+        assert ctx.split_status()["last_launch_parts"] == 8
+        key = torch.zeros(1, dtype=torch.int64, device="cuda")
+        ctx.search_grid_shard(rs, 0, 3, ws, key_out=key, blocking=False)
+        assert ctx.split_status()["last_launch_parts"] == 0
+        ctx.synchronize()
+        assert nmi.key_unpack(int(key.item())) == (io, bo)
     with nmi.NmiContext(160, 120) as ctx:                                # the same for the per-candidate entry
         ctx.set_option(ctx.OPT_PHASE_MASK, 3 | 512)
         assert ctx.eval_pair(rs[2], ws[0]) == ro[0, 2]
+        assert ctx.eval_pairs([rs[0], rs[1]], [ws[1], ws[0]]).tolist() == [ro[1, 0], ro[0, 1]]   # paused: pair by pair
+        ctx.set_option(ctx.OPT_PHASE_MASK, 3)
+        for _ in range(16):
+            ctx.eval_pair(rs[2], ws[0])
+        ctx.set_option(ctx.OPT_PHASE_MASK, 3 | 512)
+        assert ctx.eval_pairs([rs[0], rs[1]], [ws[1], ws[0]]).tolist() == [ro[1, 0], ro[0, 1]]   # batch times out, redone
+        assert ctx.split_status()["timeouts"] == 2
+    with nmi.NmiContext(160, 120) as ctx:                                # no split form fits: decided before launching
+        ctx.set_option(ctx.OPT_WORKGROUPS, 4)
         assert ctx.eval_pairs([rs[0], rs[1]], [ws[1], ws[0]]).tolist() == [ro[1, 0], ro[0, 1]]
+        assert ctx.split_status()["last_launch_parts"] == 0
+
+
+def test_stream_ticket_answers_for_its_own_split_timeout(nmi):
+    """Depth-2 stream, two small-grid tickets in flight, the SECOND one's split launch times out: wait(first)
+    returns the first's good result, wait(second) notices ITS timeout, redoes the search and returns the oracle's winner and
+    table; a ticket whose warp stack has been replaced meanwhile fails with NOT_READY and withholds its table."""
+    from oracle import binding as oc
+    from orbslam2_nmi_amd import capi, synthetic as sy
+    w, h, counts = 160, 120, (3, 1, 1)
+    K = sy.intrinsics(w, h)
+    B = sy.scene(w, h, 41)
+    F = sy.camera_frame(B, 42)
+    rs = [sy.render_stack(B, (2, 1, 1), shift_px=2 + i) for i in range(3)]
+    Ms = capi.warp_homographies(K, counts, (0.02, 0.02, 0.05))
+    with nmi.NmiContext(w, h, render_bottom_up=False) as ctx:
+        ws = ctx.warp_stack(dev(F), Ms)
+        wsh = ws.cpu().numpy()
+        with oc.rounded():
+            exp = [oc.search_grid(r, wsh, render_bottom_up=False) for r in rs]
+        hf = torch.from_numpy(F).pin_memory()
+        hr = [torch.from_numpy(r).pin_memory() for r in rs]
+        with nmi.NmiStream(ctx, 2, 3, depth=2) as st:
+            st.keep_ratings()
+            a = st.submit(hr[0], hf, Ms)
+            ctx.set_option(ctx.OPT_PHASE_MASK, 3 | 512)
+            b = st.submit(hr[1])
+            ctx.set_option(ctx.OPT_PHASE_MASK, 3)
+            assert ctx.split_status()["last_launch_parts"] == 8
+            assert st.wait(a) == exp[0][1:] and (st.ratings(a, 3, 2) == exp[0][0]).all()
+            assert ctx.split_status()["timeouts"] == 0                  # a's check did not consume b's flag
+            assert st.wait(b) == exp[1][1:] and (st.ratings(b, 3, 2) == exp[1][0]).all()
+            assert ctx.split_status()["timeouts"] == 1
+            # first of two times out, the second is an ordinary launch (paused split): each still gets its own answer
+            for _ in range(16):
+                ctx.search_grid(dev(rs[0]), ws)
+            ctx.set_option(ctx.OPT_PHASE_MASK, 3 | 512)
+            a = st.submit(hr[2])
+            ctx.set_option(ctx.OPT_PHASE_MASK, 3)
+            b = st.submit(hr[0])
+            assert st.wait(a) == exp[2][1:] and st.wait(b) == exp[0][1:]
+            assert ctx.split_status()["timeouts"] == 2
+            # a timed-out ticket whose warp stack was refilled by a later frame cannot be redone: NOT_READY, table withheld
+            for _ in range(32):
+                ctx.search_grid(dev(rs[0]), ws)
+            ctx.set_option(ctx.OPT_PHASE_MASK, 3 | 512)
+            a = st.submit(hr[1], hf, Ms)
+            ctx.set_option(ctx.OPT_PHASE_MASK, 3)
+            b = st.submit(hr[2], hf, Ms)
+            st.wait(a)                                                  # redone: buffer 1 - a's - is intact (b filled buffer 0)
+            st.wait(b)
+            for _ in range(64):
+                ctx.search_grid(dev(rs[0]), ws)
+        with nmi.NmiStream(ctx, 2, 3, depth=3) as st:
+            st.keep_ratings()
+            ctx.set_option(ctx.OPT_PHASE_MASK, 3 | 512)
+            a = st.submit(hr[1], hf, Ms)                                # buffer 0
+            ctx.set_option(ctx.OPT_PHASE_MASK, 3)
+            b = st.submit(hr[2], hf, Ms)                                # buffer 1
+            c = st.submit(hr[0], hf, Ms)                                # buffer 0 again: a's warp stack is gone
+            with pytest.raises(nmi.NmiError) as e:
+                st.wait(a)
+            assert e.value.code == capi.ERR_NOT_READY
+            with pytest.raises(nmi.NmiError):
+                st.ratings(a, 3, 2)
+            assert st.wait(b) == exp[2][1:] and st.wait(c) == exp[0][1:]
+            a = st.submit(hr[1])                                        # "submit the level again"
+            assert st.wait(a) == exp[1][1:]
 
 
 def test_invalid_arguments_fail_loudly(nmi):

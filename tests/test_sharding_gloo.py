@@ -192,3 +192,78 @@ def test_keyframe_stream_orchestration_over_gloo(world, tmp_path):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {rank} failed:\\n{out}"
         assert f"rank {rank} ok" in out
+
+
+LEVEL_WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, os.environ["NMI_ROOT"])
+    from oracle import binding as oc
+    from orbslam2_nmi_amd import sharding, synthetic as sy
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    case = os.environ["NMI_CASE"]
+    s_counts, w_counts = ((3, 3, 3), (3, 3, 3)) if case == "views27" else ((2, 1, 1), (3, 3, 1))   # 27 x 27, or 2 views x 9 warps
+    n_kf, levels = 2, 3
+    blocks = []
+    def level_inputs(kf, lvl, won):
+        # level l+1 depends on level l's winner (Tracking.cc:2088-2130: the next grid is centred on it): here the winner's
+        # index picks the scene shift of the next level, so a wrong or rank-dependent winner derails everything after it
+        nudge = sum(i for i, _ in won) % 3
+        B = sy.scene(48, 32, 700 + kf)
+        F = sy.camera_frame(B, 800 + kf)
+        rs = sy.render_stack(B, s_counts, shift_px=max(1, 3 >> lvl) + nudge)
+        ws = sy.warp_stack(F, w_counts, tuple(s / 2 ** lvl for s in (0.02, 0.02, 0.05)))
+        return rs, ws
+    def process_level(kf, lvl, won):
+        rs, ws = level_inputs(kf, lvl, won)
+        S, Wn = rs.shape[0], ws.shape[0]
+        def run_block(so, sc, wo, wc):      # this rank sees ONLY its block of views / warps
+            blocks.append((so, sc, wo, wc))
+            local, _, _ = oc.search_grid(rs[so:so + sc], ws[wo:wo + wc], render_bottom_up=False)
+            return sharding.capi.key_unpack(sharding.local_key_from_ratings(local, so, S, wo))
+        return sharding.sharded_level(run_block, S, Wn, rank, world, dist)
+    table = sharding.run_keyframes_level_sharded(n_kf, levels, process_level)
+    S_total = 27 if case == "views27" else 2
+    if case == "views27":
+        assert all(b == sharding.grid_shard(27, 27, rank, world) and b[3] == 27 for b in blocks), blocks      # render axis
+    else:
+        assert all(b[:2] == (0, 2) and b[3] < 9 for b in blocks) or world == 1, blocks                         # fewer views than ranks: warp axis
+    # the whole sequence on one rank, unsharded
+    def whole_level(kf, lvl, won):
+        rs, ws = level_inputs(kf, lvl, won)
+        _, idx, best = oc.search_grid(rs, ws, render_bottom_up=False)
+        return idx, best
+    expect = sharding.run_keyframes_level_sharded(n_kf, levels, whole_level)
+    assert (table == expect).all(), (rank, table.tolist(), expect.tolist())
+    dist.barrier(); dist.destroy_process_group()
+    print("rank", rank, "ok", table[..., 0].reshape(-1).tolist())
+""")
+
+
+@pytest.mark.parametrize("world,case", [(2, "views27"), (3, "views27"), (3, "warpaxis")])
+def test_level_sharded_orchestration_over_gloo(world, case, tmp_path):
+    """The level-sharded multi-rank form (bench.py --config stream|e2e --shard level; nmi_level_run_rccl /
+    nmi_stream_submit_block on the GPU): every rank scores only its block of each level -- 27 views over 2 / 3 ranks on the
+    render axis; 2 views over 3 ranks falls to the warp axis -- one 8-byte MAX all-reduce per level, dependent levels, and
+    the sequence of winners equals the unsharded one on every rank.  The oracle is the scorer here."""
+    script = tmp_path / "level_worker.py"
+    script.write_text(LEVEL_WORKER)
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   NMI_ROOT=ROOT, NMI_CASE=case, OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out.decode())
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {rank} failed:\\n{out}"
+        assert f"rank {rank} ok" in out
