@@ -233,6 +233,21 @@ def load_pmc_lds():
                                   "lds_active_cycles_per_wave_instruction", "conflict_free_cycles_per_wave_instruction", "source")}
 
 
+def native_comm(ctx, rank, world, dist):
+    """ncclComm_t for the product's own collectives (nmi_level_run_rccl / nmi_stream_submit_block): rank 0 draws the unique id,
+    torch.distributed ships its 128 bytes, every rank joins.  None with one rank or a non-RCCL rehearsal backend."""
+    from orbslam2_nmi_amd import capi
+    if dist is None or world == 1 or dist.get_backend() != "nccl":
+        return None
+    box = [capi.rccl_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return ctx.rccl_comm_init(box[0], rank, world)
+
+
+LEVEL_SHARDED = ("level-sharded: each level's 27 views are dealt to the ranks (render axis; the warp axis when there are fewer views "
+                 "than ranks), every rank makes its own warps, one 8-byte MAX all-reduce of the packed winner per level")
+
+
 def run_stream_config(args):
     """BASELINE.json configs[4]: 100-keyframe synthetic sequence, 3 search levels per keyframe (steps halved per level like
     NmiSearchKernel::resizeKernel), 3^6 candidates per level at 848x480, render stacks streamed from pinned host memory
@@ -261,6 +276,9 @@ def run_stream_config(args):
     st = nmi.NmiStream(ctx, 27, 27, depth=2)
     n_kf = args.keyframes
     red_dev = "cuda" if (dist is not None and dist.get_backend() == "nccl") else "cpu"
+    sharded = args.shard == "level"
+    comm = native_comm(ctx, rank, world, dist) if sharded else None
+    so, sc_, wo, wc = sharding.grid_shard(27, 27, rank, world) if sharded else (0, 27, 0, 27)
 
     def run(nk):
         table = sharding.new_keyframe_table(nk, levels)
@@ -269,16 +287,29 @@ def run_stream_config(args):
         def collect():
             kf, lvl, t = pending.pop(0)
             idx, sc = st.wait(t)
+            if sharded and comm is None and dist is not None:  # rehearsal backend: the caller owns the exchange
+                idx, sc = sharding.sharded_level(lambda *blk: (idx, sc), 27, 27, rank, world, dist)
             sharding.store_keyframe_result(table, kf, lvl, idx, sc)
 
-        for kf in sharding.keyframe_share(nk, rank, world):
+        # replicas: this rank's keyframes, whole levels.  level-sharded: every keyframe, this rank's block of every level
+        # (it uploads only its views: the H2D traffic that bounds this config is divided by the number of ranks)
+        for kf in (range(nk) if sharded else sharding.keyframe_share(nk, rank, world)):
             for lvl in range(levels):
                 p = kf % pool
-                pending.append((kf, lvl, st.submit(stacks[p * levels + lvl], frames[p], homs[p * levels + lvl])))
+                if sharded:
+                    t = st.submit(stacks[p * levels + lvl][so:so + sc_], frames[p], homs[p * levels + lvl][wo:wo + wc],
+                                  block=(so, 27, wo, 27), comm=comm)
+                else:
+                    t = st.submit(stacks[p * levels + lvl], frames[p], homs[p * levels + lvl])
+                pending.append((kf, lvl, t))
                 if len(pending) == 2:
                     collect()
         while pending:
             collect()
+        if sharded:
+            table = table.copy()
+            table[..., 0] -= 1
+            return table
         return sharding.gather_keyframe_table(table, world, dist, red_dev)
 
     run(4 * world)
@@ -289,16 +320,20 @@ def run_stream_config(args):
     evidence = rank_evidence(world, dist, local_rank)
     if rank == 0:
         evals = n_kf * levels * 729
-        h2d = n_kf * levels * (27 + 1) * w * h
+        h2d = n_kf * levels * (27 + (world if sharded else 1)) * w * h  # level-sharded: every rank uploads the frame
         print(json.dumps({"metric": "keyframes/s (BASELINE configs[4]: 848x480, 3 levels x 729 candidates, render stacks streamed H2D)",
                           "value": n_kf / dt, "unit": "keyframes/s", "evals_per_s": evals / dt, "n_gpus": world,
                           "keyframes": n_kf, "levels": levels, "h2d_GBps_all_ranks": h2d / dt / 1e9, "data": "synthetic", **evidence,
                           "higher_is_better": True, "scaling": "strong",
                           "config": {"workload": "BASELINE.json configs[4]: 100-keyframe sequence, coarse-to-fine 3 levels, double-buffered render stacks",
                                      "width": w, "height": h, "pipeline_depth": 2,
-                                     "parallelism": "replicas: keyframes dealt round-robin to ranks, winners gathered by one all-reduce"
-                                     if world > 1 else "one rank"}}))
+                                     "parallelism": "one rank" if world == 1 else LEVEL_SHARDED if sharded else
+                                     "replicas: keyframes dealt round-robin to ranks, winners gathered by one all-reduce",
+                                     "question": "latency of a live sequence (keyframes one after the other)" if sharded else
+                                     "throughput of a recorded sequence (keyframes independent)"}}))
     st.close()
+    if comm is not None:
+        capi.rccl_comm_destroy(comm)
     ctx.close()
     if dist is not None:
         dist.barrier()
@@ -319,25 +354,54 @@ def run_e2e_config(args):
     w, h, levels = 848, 480, 3
     K = sy.intrinsics(w, h)
     rp = capi.RenderParams(fx=K[0, 0], fy=K[1, 1], cx=K[0, 2], cy=K[1, 2], near_plane=5.0, far_plane=30.0, point_size=3.0)
-    # a textured plane at 10 m, ~1.3 M points (about 2 per pixel of the view), plus the frame seen from a displaced pose
+    # a textured plane at 10 m, three views wide, plus the frame seen from the grid's centre pose:
+    #   cloud (nmi_prop_RENDER 4): ~1.3 M coloured points (about 2 per pixel of the view)
+    #   mesh  (nmi_prop_RENDER 1, the reference's default, allProperties.hpp:41): --mesh-quads NX x NY quads = 2 NX NY textured triangles
     B = sy.scene(2 * w, 2 * h, 77)
-    nu, nv = int(3 * w * 0.9), int(3 * h * 0.9)
-    uu, vv = np.meshgrid(np.linspace(-w, 2 * w, nu), np.linspace(-h, 2 * h, nv))
-    xyz = np.stack([(uu - rp.cx) / rp.fx * 10.0, (vv - rp.cy) / rp.fy * 10.0, np.full_like(uu, 10.0)], -1).reshape(-1, 3).astype(np.float32)
-    red = (B[np.clip(((vv + h) / 3 * 2).astype(int), 0, 2 * h - 1), np.clip(((uu + w) / 3 * 2).astype(int), 0, 2 * w - 1)]
-           .astype(np.float32) / np.float32(256)).reshape(-1)
+    mesh = args.map == "mesh"
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
-    dx, dr = torch.from_numpy(xyz).cuda(), torch.from_numpy(red).cuda()
     ctx = nmi.NmiContext(w, h)
     ctx.set_stream(stream.cuda_stream)
+    tex = None
+    if mesh:
+        nx, ny = (int(v) for v in args.mesh_quads.lower().split("x"))
+        uu, vv = np.meshgrid(np.linspace(-w, 2 * w, nx + 1), np.linspace(-h, 2 * h, ny + 1))
+        P = np.stack([(uu - rp.cx) / rp.fx * 10.0, (vv - rp.cy) / rp.fy * 10.0, np.full_like(uu, 10.0)], -1).astype(np.float32)
+        T = np.stack([(uu + w) / (3 * w), (vv + h) / (3 * h)], -1).astype(np.float32)
+        p00, p10, p01, p11 = P[:-1, :-1], P[:-1, 1:], P[1:, :-1], P[1:, 1:]
+        t00, t10, t01, t11 = T[:-1, :-1], T[:-1, 1:], T[1:, :-1], T[1:, 1:]
+        # counter-clockwise as seen by the ORB-SLAM camera (y down): the front faces of rendering.hpp's glEnable(GL_CULL_FACE)
+        xyz = np.ascontiguousarray(np.stack([p00, p11, p10, p00, p01, p11], 2).reshape(-1, 3))
+        red = np.ascontiguousarray(np.stack([t00, t11, t10, t00, t01, t11], 2).reshape(-1, 2))   # uv
+        tex = nmi.NmiTexture(ctx, np.stack([B, B, B], -1).astype(np.uint8))
+    else:
+        nu, nv = int(3 * w * 0.9), int(3 * h * 0.9)
+        uu, vv = np.meshgrid(np.linspace(-w, 2 * w, nu), np.linspace(-h, 2 * h, nv))
+        xyz = np.stack([(uu - rp.cx) / rp.fx * 10.0, (vv - rp.cy) / rp.fy * 10.0, np.full_like(uu, 10.0)], -1).reshape(-1, 3).astype(np.float32)
+        red = (B[np.clip(((vv + h) / 3 * 2).astype(int), 0, 2 * h - 1), np.clip(((uu + w) / 3 * 2).astype(int), 0, 2 * w - 1)]
+               .astype(np.float32) / np.float32(256)).reshape(-1)
+    dx, dr = torch.from_numpy(xyz).cuda(), torch.from_numpy(red).cuda()
     Twc = np.eye(4, dtype=np.float32)  # ORB-SLAM camera axes: x right, y down, z forward (setupCam, ioData.cpp:177-197)
     pos, look, up = Twc[:3, 3], Twc[:3, 3] + Twc[:3, 2], Twc[:3, 1]
     grids = [H.SearchKernel.make([3] * 6, [s / 2 ** l for s in (0.2, 0.2, 0.5, 0.02, 0.02, 0.05)]) for l in range(levels)]
     cells = [(sx, sy, sz) for sz in range(3) for sy in range(3) for sx in range(3)]
     mvps = [np.stack([capi.render_mvp(rp, pos, look, up, H.calculate_translation(Twc, g, *c)) for c in cells]) for g in grids]
     homs = [capi.warp_homographies(K, (3, 3, 3), tuple(g.step[3:6])) for g in grids]
-    frame = torch.flip(ctx.render_points(dx, torch.sqrt(dr), capi.render_mvp(rp, pos, look, up, (0, 0, 0))[None], 3.0)[0], dims=[0]).contiguous()
+    centre_view = capi.render_mvp(rp, pos, look, up, (0, 0, 0))[None]
+    if mesh:
+        frame = ctx.render_mesh(dx, dr, tex, centre_view)[0]
+        if float((frame != 255).float().mean()) < 0.9:  # back faces are culled: turn every triangle round (swap corners 1 and 2)
+            flip = torch.tensor([0, 2, 1], device="cuda")
+            dx = dx.view(-1, 3, 3)[:, flip].reshape(-1, 3).contiguous()
+            dr = dr.view(-1, 3, 2)[:, flip].reshape(-1, 2).contiguous()
+            frame = ctx.render_mesh(dx, dr, tex, centre_view)[0]
+        if float((frame != 255).float().mean()) < 0.9:
+            sys.exit("e2e config: the mesh does not cover the view")
+        lut = torch.clamp(torch.round(255.0 * (torch.arange(256, device="cuda") / 255.0) ** 0.5), 0, 255).to(torch.uint8)  # modality gap
+        frame = lut[torch.flip(frame, dims=[0]).long()].contiguous()
+    else:
+        frame = torch.flip(ctx.render_points(dx, torch.sqrt(dr), centre_view, 3.0)[0], dims=[0]).contiguous()
     # camera noise (sigma 10 grey levels, like the config-2 workload): without it the frame is a deterministic function of
     # the render and the joint histogram collapses onto a curve, which is the LDS atomic unit's worst case, not a camera's
     noise = torch.from_numpy(np.random.default_rng(4242).normal(0.0, 10.0, (h, w)).astype(np.float32)).cuda()
@@ -345,15 +409,27 @@ def run_e2e_config(args):
     rs = torch.empty((27, h, w), dtype=torch.uint8, device="cuda")
     ws = torch.empty((27, h, w), dtype=torch.uint8, device="cuda")
 
-    level = nmi.NmiLevel(ctx, dx, dr, frame, 27, 27, 3.0) if not args.no_graph else None
+    sharded = args.shard == "level"
+    if sharded and args.no_graph:
+        sys.exit("--shard level runs the level graph (drop --no-graph)")
+    so, sc_, wo, wc = sharding.grid_shard(27, 27, rank, world) if sharded else (0, 27, 0, 27)
+    comm = native_comm(ctx, rank, world, dist) if sharded else None
+    level = nmi.NmiLevel(ctx, dx, dr, frame, sc_, wc, 3.0, texture=tex, block=(so, 27, wo, 27)) if not args.no_graph else None
 
     def keyframe():
         out = []
         for l in range(levels):
-            if level is not None:  # one hipGraphLaunch per level
+            if level is not None and comm is not None:  # graph replay + ncclAllReduce of the key, inside the library
+                out.append(level.run_rccl(mvps[l][so:so + sc_], homs[l][wo:wo + wc], comm))
+            elif level is not None and sharded and dist is not None:  # rehearsal backend: the caller owns the exchange
+                out.append(sharding.sharded_level(lambda *blk: level.run(mvps[l][so:so + sc_], homs[l][wo:wo + wc]), 27, 27, rank, world, dist))
+            elif level is not None:  # one hipGraphLaunch per level
                 out.append(level.run(mvps[l], homs[l]))
-            else:                  # the same seven operations enqueued one by one
-                ctx.render_points(dx, dr, mvps[l], 3.0, out=rs, sync=False)
+            else:                  # the same operations enqueued one by one
+                if mesh:
+                    ctx.render_mesh(dx, dr, tex, mvps[l], out=rs, sync=False)
+                else:
+                    ctx.render_points(dx, dr, mvps[l], 3.0, out=rs, sync=False)
                 ctx.warp_stack(frame, homs[l], out=ws, sync=False)
                 out.append(ctx.search_grid(rs, ws))
         return out
@@ -366,20 +442,32 @@ def run_e2e_config(args):
         sys.exit(f"rank {rank}: e2e config: unexpected coarse-level winner {res[0]}")
     red_dev = "cuda" if (dist is not None and dist.get_backend() == "nccl") else "cpu"
     n_kf = args.keyframes
-    dt, table = timed_region(lambda: sharding.run_keyframes(n_kf, levels, rank, world, lambda kf: keyframe(), dist, red_dev), dist)
+    if sharded:  # every rank takes part in every level of every keyframe, and every rank ends up with every winner
+        dt, table = timed_region(lambda: sharding.run_keyframes(n_kf, levels, 0, 1, lambda kf: keyframe()), dist)
+    else:
+        dt, table = timed_region(lambda: sharding.run_keyframes(n_kf, levels, rank, world, lambda kf: keyframe(), dist, red_dev), dist)
     if not (table[:, 0, 0] == 13 * 27 + 13).all():
         sys.exit(f"rank {rank}: e2e config: a coarse level lost the centre cell")
     evidence = rank_evidence(world, dist, local_rank)
     if rank == 0:
-        print(json.dumps({"metric": "keyframes/s (device end to end: 848x480, 3 levels x (27 cloud renders + 27 warps + 729-candidate search))",
+        what = f"27 renders of a {xyz.shape[0] // 3}-triangle textured mesh" if mesh else "27 cloud renders"
+        print(json.dumps({"metric": f"keyframes/s (device end to end: 848x480, 3 levels x ({what} + 27 warps + 729-candidate search))",
                           "value": n_kf / dt, "unit": "keyframes/s", "evals_per_s": n_kf * levels * 729 / dt,
-                          "n_gpus": world, "points": int(xyz.shape[0]), "data": "synthetic", **evidence,
-                          "ms_per_level_per_rank": dt / n_kf / levels * 1e3 * world,
+                          "n_gpus": world, "map": args.map, "triangles" if mesh else "points": int(xyz.shape[0] // 3 if mesh else xyz.shape[0]),
+                          "data": "synthetic", **evidence,
+                          "ms_per_level": dt / n_kf / levels * 1e3 * (1 if sharded else world),
                           "hip_graph": level is not None, "higher_is_better": True, "scaling": "strong",
                           "config": {"workload": "BASELINE.json configs[4] shape with the render / warp producers on the device",
-                                     "parallelism": "replicas: keyframes dealt round-robin to ranks" if world > 1 else "one rank"}}))
+                                     "parallelism": "one rank" if world == 1 else LEVEL_SHARDED if sharded else
+                                     "replicas: keyframes dealt round-robin to ranks",
+                                     "question": "latency of a live sequence (keyframes one after the other)" if sharded else
+                                     "throughput of a recorded sequence (keyframes independent)"}}))
     if level is not None:
         level.close()
+    if comm is not None:
+        capi.rccl_comm_destroy(comm)
+    if tex is not None:
+        tex.close()
     ctx.close()
     if dist is not None:
         dist.barrier()
@@ -392,6 +480,11 @@ def main():
                     help="c2 = BASELINE.json configs[1] (the headline line); c3 = configs[2] (960x540, 4096 candidates); c4 = the "
                          "per-rank share of configs[3] (848x480, 64 renders x 64 warps); stream = configs[4] shape on the local GPU")
     ap.add_argument("--keyframes", type=int, default=100)
+    ap.add_argument("--shard", default="keyframes", choices=["keyframes", "level"],
+                    help="stream / e2e configs with N > 1: keyframes = replicas, whole keyframes dealt round-robin (throughput of a recorded "
+                         "sequence); level = every level's candidates shared by the ranks, one 8-byte all-reduce per level (latency of a live one)")
+    ap.add_argument("--map", default="cloud", choices=["cloud", "mesh"], help="e2e config: coloured point cloud (nmi_prop_RENDER 4) or textured mesh (1)")
+    ap.add_argument("--mesh-quads", default="60x40", help="e2e config, --map mesh: tessellation of the plane, NXxNY quads (60x40 = 4,800 triangles)")
     ap.add_argument("--no-graph", action="store_true", help="e2e config: enqueue the level's operations one by one instead of a HIP graph")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000,

@@ -627,13 +627,15 @@ def test_split_hand_off_timeout_falls_back(nmi):
         for _ in range(15):
             assert ctx.search_grid(rs, ws) == (io, bo)
         ctx.set_option(ctx.OPT_PHASE_MASK, 3 | 512)
-        assert ctx.search_grid(rs, ws) == (io, bo)                      # (the good launches re-armed the short pause first)
-        assert ctx.split_status()["timeouts"] == 3
+        assert ctx.search_grid(rs, ws) == (io, bo)                      # the retry after the pause times out again: the pause doubles
+        st = ctx.split_status()
+        assert (st["timeouts"], st["cooldown_calls_left"], st["next_cooldown"]) == (3, 31, 64)
         # an enqueue-only call (nobody would look for a timeout) never uses the split kernel
         ctx.set_option(ctx.OPT_PHASE_MASK, 3)
-        for _ in range(20):
+        for _ in range(32):
             ctx.search_grid(rs, ws)
-        assert ctx.split_status()["last_launch_parts"] == 8
+        st = ctx.split_status()
+        assert (st["cooldown_calls_left"], st["next_cooldown"], st["last_launch_parts"]) == (0, 16, 8)
         key = torch.zeros(1, dtype=torch.int64, device="cuda")
         ctx.search_grid_shard(rs, 0, 3, ws, key_out=key, blocking=False)
         assert ctx.split_status()["last_launch_parts"] == 0

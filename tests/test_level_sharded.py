@@ -1,0 +1,155 @@
+"""Level-sharded multi-rank forms on the GPU (-m gpu; one device, so the ranks' blocks are run one after the other and their
+keys composed on the host exactly as the 8-byte MAX all-reduce composes them): nmi_level_create_block / _mesh_block,
+nmi_level_run_rccl (world 1), nmi_stream_submit_block.  The orchestration over real ranks is covered on the CPU
+(tests/test_sharding_gloo.py::test_level_sharded_orchestration_over_gloo)."""
+import numpy as np
+import pytest
+
+from orbslam2_nmi_amd import capi, sharding, synthetic as sy
+from test_render import plane_cloud, plane_mesh
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nmi():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu tests need a HIP device")
+    import orbslam2_nmi_amd as m
+    m.load_library()
+    return m
+
+
+def level_inputs(rp, w, h, lvl, s_counts=(2, 2, 2), w_counts=(3, 2, 2)):
+    from orbslam2_nmi_amd import hostapi as H
+    Twc = np.eye(4, dtype=np.float32)
+    Twc[:3, 1] = [0, -1, 0]
+    pos, look, up = Twc[:3, 3], Twc[:3, 3] + Twc[:3, 2], Twc[:3, 1]
+    g = H.SearchKernel.make([*s_counts, *w_counts], [s / 2 ** lvl for s in (0.2, 0.2, 0.5, 0.02, 0.02, 0.05)])
+    cells = [(sx, sy_, sz) for sz in range(s_counts[2]) for sy_ in range(s_counts[1]) for sx in range(s_counts[0])]
+    mvps = np.stack([capi.render_mvp(rp, pos, look, up, H.calculate_translation(Twc, g, *c)) for c in cells])
+    Ms = capi.warp_homographies(sy.intrinsics(w, h), w_counts, tuple(g.step[3:6]))
+    return (pos, look, up), mvps, Ms
+
+
+def compose(results):
+    """What the MAX all-reduce of the packed keys yields."""
+    return capi.key_unpack(max(capi.key_pack(float(s), int(i)) if i >= 0 else 0 for i, s in results))
+
+
+@pytest.mark.parametrize("mesh", [False, True])
+def test_block_levels_compose_to_the_level(nmi, mesh):
+    w, h, S, Wn = 160, 120, 8, 12
+    with nmi.NmiContext(w, h) as ctx:
+        if mesh:
+            xyz, attr, rgb, rp = plane_mesh(w, h, nx=12, ny=9)
+            tex = nmi.NmiTexture(ctx, rgb)
+        else:
+            xyz, attr, rp = plane_cloud(w, h, density=2.0)
+            tex = None
+        dx, da = torch.from_numpy(xyz).cuda(), torch.from_numpy(attr).cuda()
+        cam, mvps0, _ = level_inputs(rp, w, h, 0)
+        view = capi.render_mvp(rp, *cam, (0.05, 0, 0))[None]
+        fr = ctx.render_mesh(dx, da, tex, view)[0] if mesh else ctx.render_points(dx, torch.sqrt(da), view, 3.0)[0]
+        frame = torch.flip(fr, dims=[0]).contiguous()
+
+        def make(S_, Wn_, block=None):
+            return nmi.NmiLevel(ctx, dx, da, frame, S_, Wn_, 3.0, texture=tex, block=block)
+
+        full = make(S, Wn)
+        whole = make(S, Wn, block=(0, S, 0, Wn))                     # block form with (0, 1): today's level bit for bit
+        for lvl in range(3):
+            _, mvps, Ms = level_inputs(rp, w, h, lvl)
+            ref = full.run(mvps, Ms)
+            r_ref, w_ref, t_ref = full.outputs()
+            assert whole.run(mvps, Ms) == ref
+            r, v, t = whole.outputs()
+            assert (r == r_ref).all() and (v == w_ref).all() and (t.view(np.uint32) == t_ref.view(np.uint32)).all()
+            for world in (2, 3):                                     # render axis: 8 views over 2 / 3 ranks
+                got = []
+                for rank in range(world):
+                    so, sc, wo, wc = sharding.grid_shard(S, Wn, rank, world)
+                    assert (wo, wc) == (0, Wn)
+                    with make(sc, wc, block=(so, S, wo, Wn)) as blk:
+                        got.append(blk.run(mvps[so:so + sc], Ms[wo:wo + wc]))
+                        r, v, t = blk.outputs()
+                        assert (r == r_ref[so:so + sc]).all() and (v == w_ref).all()
+                        assert (t.view(np.uint32) == t_ref[:, so:so + sc].view(np.uint32)).all()
+                assert compose(got) == ref, (lvl, world, got, ref)
+            got = []                                                 # warp axis (what S < ranks falls to): 12 warps over 2 ranks
+            for wo, wc in ((0, 6), (6, 6)):
+                with make(S, wc, block=(0, S, wo, Wn)) as blk:
+                    got.append(blk.run(mvps, Ms[wo:wo + wc]))
+                    _, v, t = blk.outputs()
+                    assert (v == w_ref[wo:wo + wc]).all() and (t.view(np.uint32) == t_ref[wo:wo + wc].view(np.uint32)).all()
+            assert compose(got) == ref
+        # an empty block (more ranks than cells): no candidate, and it still has a key for the collective
+        with make(0, Wn, block=(S, S, 0, Wn)) as blk:
+            assert blk.run(mvps[:0], Ms) == (-1, np.float32(0))
+            comm = ctx.rccl_comm_init(capi.rccl_unique_id(), 0, 1)
+            try:
+                assert blk.run_rccl(mvps[:0], Ms, comm) == (-1, np.float32(0))
+                _, mvps, Ms = level_inputs(rp, w, h, 1)
+                assert whole.run_rccl(mvps, Ms, comm) == full.run(mvps, Ms)     # graph -> ncclAllReduce -> winner (one rank)
+                with make(3, Wn, block=(5, S, 0, Wn)) as tail:
+                    a = tail.run(mvps[5:], Ms)
+                    assert tail.run_rccl(mvps[5:], Ms, comm) == a and a[0] % S >= 5   # global index of a cell of the block
+            finally:
+                capi.rccl_comm_destroy(comm)
+        full.close()
+        whole.close()
+        if tex is not None:
+            tex.close()
+    with pytest.raises(nmi.NmiError):
+        with nmi.NmiContext(w, h) as ctx:
+            d = torch.zeros(4, 3, device="cuda")
+            nmi.NmiLevel(ctx, d, d[:, 0].contiguous(), torch.zeros(h, w, dtype=torch.uint8, device="cuda"), 4, 4, 3.0, block=(6, 8, 0, 4))
+
+
+def test_stream_blocks_compose_to_the_level(nmi):
+    """nmi_stream_submit_block: a rank uploads and scores only its block of the render stack; the blocks' keys compose to the
+    level's winner and their rating tables are the slices of the level's table; with a communicator (one rank here) the
+    ticket completes with the reduced key."""
+    w, h, counts = 160, 120, (2, 2, 2)
+    K = sy.intrinsics(w, h)
+    B = sy.scene(w, h, 300)
+    F = sy.camera_frame(B, 400)
+    S, Wn = 8, 12
+    with nmi.NmiContext(w, h, render_bottom_up=False) as ctx:
+        hf = torch.from_numpy(F).pin_memory()
+        comm = ctx.rccl_comm_init(capi.rccl_unique_id(), 0, 1)
+        try:
+            with nmi.NmiStream(ctx, S, Wn, depth=2) as st:
+                st.keep_ratings()
+                for lvl in range(3):
+                    rs = sy.render_stack(B, counts, shift_px=max(1, 4 >> lvl))
+                    Ms = capi.warp_homographies(K, (3, 2, 2), tuple(s / 2 ** lvl for s in (0.02, 0.02, 0.05)))
+                    hr = torch.from_numpy(rs).pin_memory()
+                    t = st.submit(hr, hf, Ms)
+                    ref = st.wait(t)
+                    tab = st.ratings(t, Wn, S)
+                    assert ref == ctx.search_grid(torch.from_numpy(rs).cuda(), ctx.warp_stack(torch.from_numpy(F).cuda(), Ms))
+                    for world in (2, 3):
+                        tickets = []
+                        for rank in range(world):       # two blocks in flight (depth 2), then the third
+                            so, sc, wo, wc = sharding.grid_shard(S, Wn, rank, world)
+                            if len(tickets) == 2:
+                                tickets[0] = (st.wait(tickets[0][0]), *tickets[0][1:])
+                            tickets.append((st.submit(hr[so:so + sc], hf, Ms, block=(so, S, wo, Wn)), so, sc))
+                        got = []
+                        for tk, so, sc in tickets:
+                            res = tk if isinstance(tk, tuple) else st.wait(tk)
+                            got.append(res)
+                        assert compose(got) == ref, (lvl, world, got, ref)
+                    so, sc = 3, 5
+                    t = st.submit(hr[so:so + sc], hf, Ms[4:10], block=(so, S, 4, Wn), comm=comm)   # a block of both axes, reduced
+                    idx, score = st.wait(t)
+                    blk = tab[4:10, so:so + sc]
+                    assert (st.ratings(t, 6, sc).view(np.uint32) == blk.view(np.uint32)).all()
+                    wi, si = np.unravel_index(int(np.argmax(blk)), blk.shape)
+                    assert (idx, score) == ((4 + wi) * S + so + si, blk.max())
+                    t = st.submit(hr[:0], block=(S, S, 4, Wn), comm=comm)                          # empty block: only the exchange
+                    assert st.wait(t) == (-1, np.float32(0))
+        finally:
+            capi.rccl_comm_destroy(comm)
