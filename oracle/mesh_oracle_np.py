@@ -4,7 +4,9 @@ Restates Rendering<1>::renderToTextureOnGPU (Thirdparty/Localization/rendering.h
 ShadingWithTexture.* (luma 0.299/0.587/0.114 of the texture sample) and the texture state of loadBMP_custom
 (texture.cpp:31-96: GL_REPEAT, GL_LINEAR, GL_LINEAR_MIPMAP_LINEAR, glGenerateMipmap) with the OpenGL 3.3 specification's
 rules in fp32: pixel centres at +0.5, top-left fill rule, back-face culling (front = counter-clockwise), perspective-
-correct attributes, isotropic LOD from per-pixel uv differences, 2x2-box mip levels rounded to RGB8, and clipping of
+correct attributes (u/w, v/w, 1/w as planes over the window, one reciprocal per sample point), visibility by 24-bit depth
+with GL_LESS (among equal depths the triangle drawn first), isotropic LOD from per-pixel uv differences, 2x2-box mip levels
+rounded to RGB8, and clipping of
 triangles against the near plane in clip space (GL clips primitives to the view volume before the perspective divide:
 implied by glEnable(GL_DEPTH_TEST) / glDrawArrays(GL_TRIANGLES), rendering.hpp:294-300,619): Sutherland-Hodgman on
 z_clip >= -w_clip, new corners interpolated from the inside corner towards the outside one.
@@ -57,7 +59,7 @@ def render_mesh(xyz, uv, levels, mvp_colmajor, width, height):
     m = np.asarray(mvp_colmajor, f32)
     P = np.asarray(xyz, f32).reshape(-1, 3, 3)
     T = np.asarray(uv, f32).reshape(-1, 3, 2)
-    zbuf = np.full((height, width), 0xFFFFFFFF, np.uint32)
+    zbuf = np.full((height, width), 0xFFFFFFFFFF, np.uint64)   # depth << 8 | grey; empty: a depth no fragment reaches, grey 255
     for tri in range(P.shape[0]):
         x, y, z = P[tri, :, 0], P[tri, :, 1], P[tri, :, 2]
         cx = (m[0] * x + m[4] * y) + (m[8] * z + m[12])
@@ -67,7 +69,7 @@ def render_mesh(xyz, uv, levels, mvp_colmajor, width, height):
         tu, tv = T[tri, :, 0], T[tri, :, 1]
         for sub in _clip_near(cx, cy, cz, cw, tu, tv):
             _raster(zbuf, levels, width, height, *sub)
-    return (zbuf & np.uint32(0xFF)).astype(np.uint8)
+    return (zbuf & np.uint64(0xFF)).astype(np.uint8)
 
 
 def _clip_near(cx, cy, cz, cw, tu, tv):
@@ -125,24 +127,48 @@ def _raster(zbuf, levels, width, height, cx, cy, cz, cw, tu, tv):
         fxp = xx.astype(f32) + f32(0.5)
         fyp = yy.astype(f32) + f32(0.5)
 
-        def attrs(px, py):
-            b = [(ex[k] * (py - yw[(k + 1) % 3]) - ey[k] * (px - xw[(k + 1) % 3])) * inv_area for k in range(3)]
-            zz = (b[0] * zw[0] + b[1] * zw[1]) + b[2] * zw[2]
-            q = (b[0] * iw[0] + b[1] * iw[1]) + b[2] * iw[2]
-            u = ((b[0] * tu[0] * iw[0] + b[1] * tu[1] * iw[1]) + b[2] * tu[2] * iw[2]) / q
-            v = ((b[0] * tv[0] * iw[0] + b[1] * tv[1] * iw[1]) + b[2] * tv[2] * iw[2]) / q
-            return b, zz, u, v
+        def weights(px, py):
+            return [(ex[k] * (py - yw[(k + 1) % 3]) - ey[k] * (px - xw[(k + 1) % 3])) * inv_area for k in range(3)]
 
-        with np.errstate(divide="ignore", invalid="ignore"):
-            b, zz, u, v = attrs(fxp, fyp)
-            inside = np.ones(fxp.shape, bool)
-            for k in range(3):
-                inside &= (b[k] > 0) | ((b[k] == 0) & own[k])
-            inside &= (zz >= 0) & (zz <= 1)
-            if not inside.any():
-                return
-            _, _, ux, vx = attrs(fxp + f32(1.0), fyp)
-            _, _, uy, vy = attrs(fxp, fyp + f32(1.0))
+        # coverage and depth: barycentric weights per pixel (tri_cover, nmi_mesh.hip)
+        b = weights(fxp, fyp)
+        zz = (b[0] * zw[0] + b[1] * zw[1]) + b[2] * zw[2]
+        inside = np.ones(fxp.shape, bool)
+        for k in range(3):
+            inside &= (b[k] > 0) | ((b[k] == 0) & own[k])
+        inside &= (zz >= 0) & (zz <= 1)
+        if not inside.any():
+            return
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            depth = np.minimum((zz * f32(16777215.0) + f32(0.5)).astype(np.uint32), np.uint32(0xFFFFFF))
+        # Visibility: GL_LESS keeps the fragment drawn first among equal depths, and triangles arrive here in draw order, so
+        # a fragment wins only with a strictly smaller depth (the key depth << 40 | triangle << 10 | ... of nmi_mesh.hip).
+        sub = zbuf[y_lo:y_hi + 1, x_lo:x_hi + 1]
+        win = inside & (depth.astype(np.uint64) < (sub >> np.uint64(8)))
+        if not win.any():
+            return
+        # attributes: u/w, v/w and 1/w as planes about the centre of the box's first pixel (tri_planes / shade_pixel)
+        xr, yr = f32(x_lo) + f32(0.5), f32(y_lo) + f32(0.5)
+        b0 = weights(xr, yr)
+        bx = [(-ey[k]) * inv_area for k in range(3)]
+        by = [ex[k] * inv_area for k in range(3)]
+        sc = [tu[k] * iw[k] for k in range(3)]
+        rc = [tv[k] * iw[k] for k in range(3)]
+
+        def plane(g):
+            return ((b0[0] * g[0] + b0[1] * g[1]) + b0[2] * g[2], (bx[0] * g[0] + bx[1] * g[1]) + bx[2] * g[2],
+                    (by[0] * g[0] + by[1] * g[1]) + by[2] * g[2])
+
+        (s0, sx, sy), (r0, rx, ry), (q0, qx, qy) = plane(sc), plane(rc), plane(iw)
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            dx, dy = fxp - xr, fyp - yr
+            S = (s0 + sx * dx) + sy * dy
+            R = (r0 + rx * dx) + ry * dy
+            Q = (q0 + qx * dx) + qy * dy
+            iq, iqx, iqy = f32(1.0) / Q, f32(1.0) / (Q + qx), f32(1.0) / (Q + qy)
+            u, v = S * iq, R * iq
+            ux, vx = (S + sx) * iqx, (R + rx) * iqx
+            uy, vy = (S + sy) * iqy, (R + ry) * iqy
             dudx, dvdx, dudy, dvdy = (ux - u) * tw, (vx - v) * th, (uy - u) * tw, (vy - v) * th
             rho = np.maximum(np.sqrt(dudx * dudx + dvdx * dvdx), np.sqrt(dudy * dudy + dvdy * dvdy))
             lam = np.log2(rho).astype(f32)
@@ -152,17 +178,15 @@ def _raster(zbuf, levels, width, height, cx, cy, cz, cw, tu, tv):
                 lc = np.minimum(lam, f32(nlev - 1))
                 l0 = np.floor(lc).astype(np.int64)
                 fr = lc - l0.astype(f32)
-                for L in np.unique(l0[mini & inside]):
+                for L in np.unique(l0[mini & win]):
                     sel = mini & (l0 == L)
                     L1 = min(int(L) + 1, nlev - 1)
-                    s0 = _bilinear(levels[int(L)], u, v)
-                    s1 = _bilinear(levels[L1], u, v)
-                    luma = np.where(sel, s0 + (s1 - s0) * fr, luma)
+                    s0_ = _bilinear(levels[int(L)], u, v)
+                    s1_ = _bilinear(levels[L1], u, v)
+                    luma = np.where(sel, s0_ + (s1_ - s0_) * fr, luma)
             colour = (np.clip(luma, 0, 1) * f32(255.0) + f32(0.5)).astype(np.uint32)
-            depth = (zz * f32(16777215.0) + f32(0.5)).astype(np.uint32)
-        frag = (depth << np.uint32(8)) | colour
-        sub = zbuf[y_lo:y_hi + 1, x_lo:x_hi + 1]
-        sub[inside] = np.minimum(sub[inside], frag[inside])
+        frag = (depth.astype(np.uint64) << np.uint64(8)) | colour.astype(np.uint64)
+        sub[win] = frag[win]
 
 
 def render_stack(xyz, uv, levels, mvps, width, height):

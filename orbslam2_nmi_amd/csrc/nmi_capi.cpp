@@ -594,9 +594,7 @@ int nmi_destroy(nmi_ctx *ctx)
     if (ctx->d_pair_rating) (void)hipFree(ctx->d_pair_rating);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_zbuf) (void)hipFree(ctx->d_zbuf);
-    if (ctx->d_tile_queue) (void)hipFree(ctx->d_tile_queue);
-    if (ctx->d_tile_state) (void)hipFree(ctx->d_tile_state);
-    if (ctx->d_clip_queue) (void)hipFree(ctx->d_clip_queue);
+    mesh_work_free(&ctx->mesh);
     for (int i = 0; i < StagingRing::kSlots; ++i) {
         if (ctx->mvp_ring.d[i]) (void)hipFree(ctx->mvp_ring.d[i]);
         if (ctx->mvp_ring.h[i]) (void)hipHostFree(ctx->mvp_ring.h[i]);

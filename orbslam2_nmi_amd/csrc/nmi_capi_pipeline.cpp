@@ -22,7 +22,9 @@ struct nmi_level {
     int S = 0, Wn = 0, size = 1;                // this rank's block: S views x Wn warps ...
     int s_offset = 0, S_total = 0, w_offset = 0, Wn_total = 0;  // ... of an S_total x Wn_total level (block == level on one rank)
     uint8_t *d_renders = nullptr, *d_warps = nullptr;
-    uint32_t *d_zbuf = nullptr;
+    uint32_t *d_zbuf = nullptr;                 // point cloud: anchor buffer
+    nmi::MeshWork mesh;                         // textured mesh: the renderer's work area (kept clean by the renderer itself)
+    bool is_mesh = false;
     float *d_mvps = nullptr, *h_mvps = nullptr, *d_coeffs = nullptr, *h_coeffs = nullptr;
     int *d_order = nullptr;
     float *d_ratings = nullptr;                 // [Wn][S] rating table of the latest replay
@@ -52,6 +54,7 @@ int nmi_level_destroy(nmi_level *lv)
     if (lv->ev_fork) (void)hipEventDestroy(lv->ev_fork);
     if (lv->ev_join) (void)hipEventDestroy(lv->ev_join);
     if (lv->side) (void)hipStreamDestroy(lv->side);
+    mesh_work_free(&lv->mesh);
     delete lv;
     return NMI_OK;
 }
@@ -80,10 +83,6 @@ static int level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_attr, i
     *out = nullptr;
     ctx->detail.clear();
     DeviceGuard guard(ctx->device);
-    if (tex) {
-        const int rq = ensure_tile_queue(ctx);
-        if (rq != NMI_OK) return rq;
-    }
     nmi_level *lv = new (std::nothrow) nmi_level;
     if (!lv) return NMI_ERR_INVALID_ARGUMENT;
     lv->ctx = ctx;
@@ -118,7 +117,12 @@ static int level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_attr, i
     };
     ok(hipMalloc((void **)&lv->d_renders, npix * S));
     ok(hipMalloc((void **)&lv->d_warps, npix * Wn));
-    ok(hipMalloc((void **)&lv->d_zbuf, nmi::render_zbuf_words(S, p.width, p.height, lv->size) * sizeof(uint32_t)));
+    lv->is_mesh = tex != nullptr;
+    if (tex) {
+        if (mesh_work_alloc(ctx, S, &lv->mesh) != NMI_OK) e = hipErrorOutOfMemory;
+    } else {
+        ok(hipMalloc((void **)&lv->d_zbuf, nmi::render_zbuf_words(S, p.width, p.height, lv->size) * sizeof(uint32_t)));
+    }
     ok(hipMalloc((void **)&lv->d_mvps, (size_t)S * 16 * sizeof(float)));
     ok(hipMalloc((void **)&lv->d_coeffs, (size_t)Wn * 9 * sizeof(float)));
     ok(hipMalloc((void **)&lv->d_order, (size_t)total * sizeof(int)));
@@ -178,17 +182,17 @@ static int level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_attr, i
 
     hipStream_t st = ctx->stream;
     if (e == hipSuccess && ok(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal))) {
+        // (mesh: nothing to clear -- the renderer leaves its work area clean)
         ok(nmi::launch_level_prep(hd_mvps, lv->d_mvps, S * 16, hd_coeffs, lv->d_coeffs, Wn * 9, lv->d_key, lv->d_zbuf,
-                                  nmi::render_zbuf_words(S, p.width, p.height, lv->size), st));
+                                  tex ? 0 : nmi::render_zbuf_words(S, p.width, p.height, lv->size), st));
         ok(hipEventRecord(lv->ev_fork, st));
         ok(hipStreamWaitEvent(lv->side, lv->ev_fork, 0));
         ok(nmi::launch_warp(d_frame, lv->d_coeffs, lv->d_warps, p.width, p.height, Wn, lv->side));
         ok(hipEventRecord(lv->ev_join, lv->side));
         if (tex)
-            ok(nmi::launch_render_mesh(d_xyz, d_attr, n_points, tex->d_luma, tex->levels, tex->w, tex->h, tex->off, lv->d_mvps, S, lv->d_zbuf,
-                                       lv->d_renders, p.width, p.height, ctx->d_tile_queue,
-                                       ctx->tile_queue_limit < ctx->tile_queue_cap ? ctx->tile_queue_limit : ctx->tile_queue_cap,
-                                       ctx->d_tile_state, ctx->d_clip_queue, ctx->clip_queue_limit < ctx->clip_queue_cap ? ctx->clip_queue_limit : ctx->clip_queue_cap, st, /*clear_first=*/false));
+            ok(nmi::launch_render_mesh(d_xyz, d_attr, n_points, tex->d_luma, tex->levels, tex->w, tex->h, tex->off, lv->d_mvps, S, lv->mesh, S,
+                                       (int)(ctx->tile_queue_limit < 511 ? ctx->tile_queue_limit : 511), ctx->clip_queue_limit, lv->d_renders,
+                                       p.width, p.height, st));
         else
             ok(nmi::launch_render_points(d_xyz, d_red, n_points, lv->d_mvps, S, lv->d_zbuf, lv->d_renders, p.width, p.height, lv->size, st,
                                          /*clear_first=*/false));

@@ -6,23 +6,42 @@ using namespace nmi_internal;
 
 namespace nmi_internal {
 
-// Work queue of the mesh renderer's large-triangle pass: 4 M (triangle, view, 64x64 tile) items = 32 MiB, allocated on
-// first use.  Meshes that need more (the lanes of the first pass then shade the excess themselves) are far beyond a map
-// of textured facades.
-int ensure_tile_queue(nmi_ctx *ctx)
+// Buffers of the mesh renderer (nmi_mesh.hip) for S views: 8 bytes per pixel of visibility keys for the direct path, the
+// tile bins (at most 32 MiB) and their state words, the queue of (triangle, view) pairs crossing the near plane.
+int mesh_work_alloc(nmi_ctx *ctx, int S, nmi::MeshWork *w)
 {
-    // each of the three allocations is made when missing: a failure half-way must not leave a context that skips the rest for good
-    if (!ctx->d_tile_queue) {
-        constexpr unsigned long long kItems = 4ull << 20;
-        NMI_HIP_TRY(ctx, hipMalloc(&ctx->d_tile_queue, (size_t)kItems * nmi::mesh_tile_item_bytes()));
-        ctx->tile_queue_cap = kItems;
+    const int width = ctx->params.width, height = ctx->params.height;
+    constexpr unsigned long long kClipItems = 1ull << 18;  // beyond it the clip pass rescans the mesh
+    NMI_HIP_TRY(ctx, hipMalloc((void **)&w->zbuf, nmi::mesh_zbuf_bytes(S, width, height)));
+    NMI_HIP_TRY(ctx, hipMalloc((void **)&w->bins, nmi::mesh_bins_bytes(S, width, height)));
+    NMI_HIP_TRY(ctx, hipMalloc((void **)&w->state, nmi::mesh_state_bytes(S, width, height)));
+    NMI_HIP_TRY(ctx, hipMalloc(&w->clip_queue, (size_t)kClipItems * nmi::mesh_clip_item_bytes()));
+    w->clip_cap = kClipItems;
+    NMI_HIP_TRY(ctx, hipMalloc((void **)&w->clip_state, 2 * sizeof(unsigned long long)));
+    NMI_HIP_TRY(ctx, nmi::launch_mesh_clear(*w, S, width, height, ctx->stream));
+    return NMI_OK;
+}
+
+void mesh_work_free(nmi::MeshWork *w)
+{
+    void *all[] = {w->zbuf, w->bins, w->state, w->clip_queue, w->clip_state};
+    for (void *q : all)
+        if (q) (void)hipFree(q);
+    *w = nmi::MeshWork{};
+}
+
+int ensure_mesh_work(nmi_ctx *ctx, int S)
+{
+    if (S <= ctx->mesh_views) return NMI_OK;
+    if (ctx->mesh_views) NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    mesh_work_free(&ctx->mesh);
+    ctx->mesh_views = 0;
+    const int rc = mesh_work_alloc(ctx, S, &ctx->mesh);
+    if (rc != NMI_OK) {
+        mesh_work_free(&ctx->mesh);
+        return rc;
     }
-    if (!ctx->d_tile_state) NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tile_state, 4 * sizeof(unsigned long long)));
-    if (!ctx->d_clip_queue) {
-        constexpr unsigned long long kClipItems = 1ull << 18;  // (triangle, view) pairs crossing the near plane; beyond it: rescan
-        NMI_HIP_TRY(ctx, hipMalloc(&ctx->d_clip_queue, (size_t)kClipItems * nmi::mesh_clip_item_bytes()));
-        ctx->clip_queue_cap = kClipItems;
-    }
+    ctx->mesh_views = S;
     return NMI_OK;
 }
 
@@ -249,24 +268,20 @@ int nmi_render_mesh(nmi_ctx *ctx, const float *d_xyz, const float *d_uv, int64_t
         return NMI_ERR_INVALID_ARGUMENT;
     ctx->detail.clear();
     DeviceGuard guard(ctx->device);
-    const int64_t need = (int64_t)S * ctx->npix;
-    if (need > ctx->zbuf_cap) {
-        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->d_zbuf) NMI_HIP_TRY(ctx, hipFree(ctx->d_zbuf));
-        ctx->d_zbuf = nullptr;
-        ctx->zbuf_cap = 0;
-        NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_zbuf, (size_t)need * sizeof(uint32_t)));
-        ctx->zbuf_cap = need;
-    }
-    int rq = ensure_tile_queue(ctx);
+    // (the bins' geometry depends on the number of views: a context renders with the work area of its largest stack so far,
+    // laid out for that many views; the first S of them are used)
+    int rq = ensure_mesh_work(ctx, S);
     if (rq != NMI_OK) return rq;
     float *d_mvps = nullptr;
     int rc = stage_floats(ctx, ctx->mvp_ring, h_mvps, (size_t)S * 16, &d_mvps);
     if (rc != NMI_OK) return rc;
-    NMI_HIP_TRY(ctx, nmi::launch_render_mesh(d_xyz, d_uv, n_triangles, tex->d_luma, tex->levels, tex->w, tex->h, tex->off, d_mvps, S,
-                                             ctx->d_zbuf, d_render_stack, ctx->params.width, ctx->params.height, ctx->d_tile_queue,
-                                             ctx->tile_queue_limit < ctx->tile_queue_cap ? ctx->tile_queue_limit : ctx->tile_queue_cap,
-                                             ctx->d_tile_state, ctx->d_clip_queue, ctx->clip_queue_limit < ctx->clip_queue_cap ? ctx->clip_queue_limit : ctx->clip_queue_cap, ctx->stream));
+    const hipError_t e = nmi::launch_render_mesh(d_xyz, d_uv, n_triangles, tex->d_luma, tex->levels, tex->w, tex->h, tex->off, d_mvps, S, ctx->mesh,
+                                                 ctx->mesh_views, (int)(ctx->tile_queue_limit < 511 ? ctx->tile_queue_limit : 511), ctx->clip_queue_limit,
+                                                 d_render_stack, ctx->params.width, ctx->params.height, ctx->stream);
+    if (e != hipSuccess) {
+        ctx->mesh_views = 0;  // whatever state the buffers are in: allocate and clear afresh next time
+        return hip_fail(ctx, e, "launch_render_mesh");
+    }
     return NMI_OK;
 }
 

@@ -104,13 +104,10 @@ struct nmi_ctx {
     int split_mode = -1;                  // NMI_OPT_SPLIT: -1 automatic, 0 never, 2 / 4 / 8 parts whenever the grid fits
     uint32_t *d_zbuf = nullptr;           // depth|colour anchor buffers of the point-cloud renderer (padded, per view)
     int64_t zbuf_cap = 0;
-    void *d_tile_queue = nullptr;          // mesh renderer: (triangle, view, tile) work items of large triangles
-    unsigned long long tile_queue_cap = 0;      // allocated items
-    unsigned long long tile_queue_limit = 4ull << 20;  // NMI_OPT_TILE_QUEUE
-    unsigned long long *d_tile_state = nullptr;  // [4] tile items claimed / ~(first claim that did not fit) / clip items claimed / -
-    void *d_clip_queue = nullptr;          // mesh renderer: (triangle, view) pairs that cross the near plane
-    unsigned long long clip_queue_cap = 0;
-    unsigned long long clip_queue_limit = ~0ull;  // NMI_OPT_CLIP_QUEUE
+    nmi::MeshWork mesh;                    // mesh renderer (nmi_render_mesh): bins, their state, key buffer, clip queue -- for mesh_views views
+    int mesh_views = 0;
+    unsigned long long tile_queue_limit = 4ull << 20;  // NMI_OPT_TILE_QUEUE: usable entries per bin (capped by the bins' size)
+    unsigned long long clip_queue_limit = ~0ull;       // NMI_OPT_CLIP_QUEUE
     StagingRing mvp_ring;
     uint32_t *d_scratch = nullptr;        // drained-counter slabs of the pipelined kernel
     int scratch_workgroups = 0;
@@ -142,7 +139,10 @@ struct nmi_texture {
 
 namespace nmi_internal {
 
-int ensure_tile_queue(nmi_ctx *ctx);
+// Device buffers of the mesh renderer for S views, allocated and brought to their clean state (the renderer keeps them clean).
+int mesh_work_alloc(nmi_ctx *ctx, int S, nmi::MeshWork *w);
+void mesh_work_free(nmi::MeshWork *w);
+int ensure_mesh_work(nmi_ctx *ctx, int S);  // the context's own, grown on demand
 int level_enqueue(nmi_level *lv, const float *h_mvps, const double *h_forward, const unsigned long long **d_key);
 nmi_ctx *level_ctx(nmi_level *lv);
 // ncclAllReduce(ncclMax, ncclUint64) of one 8-byte key on the context's stream, out of place (nmi_capi_rccl.cpp)

@@ -124,15 +124,27 @@ size_t grid_kernel_scratch_bytes(int workgroups);
 hipError_t launch_warp(const uint8_t *frame, const float *coeffs /*[Wn][9] inverse maps*/, uint8_t *out, int width,
                        int height, int Wn, hipStream_t stream);
 
-// tile_queue: device memory for tile_queue_cap work items of mesh_tile_item_bytes() each (large triangles are shaded by
-// a second kernel, one wavefront per 64x64 tile); queue_state: two device words; either may be null (everything in-lane).
+// Textured-mesh renderer (nmi_mesh.hip): a binned, deferred rasteriser.  MeshWork = its device buffers, owned by a context
+// or by a level; zbuf must be all ones and state all zero before a render (launch_mesh_clear once after allocation) and
+// the renderer leaves them so.  bin_cap_limit: usable entries per bin (NMI_OPT_TILE_QUEUE; 0 = every triangle is
+// rasterised by its own lane); clip_cap_limit likewise for the queue of triangles crossing the near plane.
+struct MeshWork {
+    unsigned long long *zbuf = nullptr;        // [S][H][W] visibility keys of the direct path (mesh_zbuf_bytes)
+    uint32_t *bins = nullptr;                  // [S][tiles][stride] bin entries (mesh_bins_bytes)
+    uint32_t *state = nullptr;                 // [S][tiles][2] entries appended / tile has keys in zbuf (mesh_state_bytes)
+    void *clip_queue = nullptr;                // (triangle, view) pairs that cross the near plane
+    unsigned long long clip_cap = 0;
+    unsigned long long *clip_state = nullptr;  // [2]
+};
+size_t mesh_zbuf_bytes(int S, int width, int height);
+size_t mesh_bins_bytes(int S, int width, int height);
+size_t mesh_state_bytes(int S, int width, int height);
+size_t mesh_clip_item_bytes();
+hipError_t launch_mesh_clear(const MeshWork &w, int S, int width, int height, hipStream_t stream);
 hipError_t launch_render_mesh(const float *xyz, const float *uv, long long ntri, const float *luma, int levels, const int *lw,
-                              const int *lh, const long long *loff, const float *mvps /*[S][16]*/, int S, uint32_t *zbuf /*[S][H][W]*/,
-                              uint8_t *out, int width, int height, void *tile_queue, unsigned long long tile_queue_cap,
-                              unsigned long long *queue_state /*[4]*/, void *clip_queue, unsigned long long clip_queue_cap,
-                              hipStream_t stream, bool clear_first = true);
-size_t mesh_tile_item_bytes();
-size_t mesh_clip_item_bytes();  // items of the queue that hands triangles crossing the near plane to the clip kernel
+                              const int *lh, const long long *loff, const float *mvps /*[S][16]*/, int S, const MeshWork &w,
+                              int layout_views /* views the work area was allocated for (>= S) */, int bin_cap_limit,
+                              unsigned long long clip_cap_limit, uint8_t *out, int width, int height, hipStream_t stream);
 // Words between rows of the renderers' anchor / depth buffer: the padded width, rounded so that the resolve pass can
 // read 8 consecutive anchors of any output quad with two aligned 16-byte loads (point sizes > 1); width for size 1.
 inline int zbuf_stride(int width, int size) { return size > 1 ? ((width + size - 1 + 3) & ~3) + 4 : width; }
