@@ -170,8 +170,8 @@ def _raster(zbuf, levels, width, height, cx, cy, cz, cw, tu, tv):
             ux, vx = (S + sx) * iqx, (R + rx) * iqx
             uy, vy = (S + sy) * iqy, (R + ry) * iqy
             dudx, dvdx, dudy, dvdy = (ux - u) * tw, (vx - v) * th, (uy - u) * tw, (vy - v) * th
-            rho = np.maximum(np.sqrt(dudx * dudx + dvdx * dvdx), np.sqrt(dudy * dudy + dvdy * dvdy))
-            lam = np.log2(rho).astype(f32)
+            rho2 = np.maximum(dudx * dudx + dvdx * dvdx, dudy * dudy + dvdy * dvdy)
+            lam = f32(0.5) * np.log2(rho2).astype(f32)      # log2 of the longer footprint axis = half the log2 of its square
             luma = _bilinear(levels[0], u, v)
             mini = lam > 0
             if mini.any():

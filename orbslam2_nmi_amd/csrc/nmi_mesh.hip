@@ -21,12 +21,12 @@
 //                         touches (wave-aggregated appends: neighbours in the mesh land in the same tile); one that crosses
 //                         the near plane goes to a small queue for
 //   nmi_mesh_clip_kernel  which clips it (Sutherland-Hodgman in clip space) and treats the 1 or 2 pieces the same way.
-//   nmi_mesh_tile_kernel  one 1024-lane workgroup per (view, tile): the tile's 4096 visibility keys live in LDS (32 KiB, no
-//                         device atomics, no clear pass), lane j sets up bin entry j into an LDS record, the 16 wavefronts
-//                         share the records' pixel boxes as 64-pixel stamps and resolve visibility with ds_min_u64, then
+//   nmi_mesh_tile_kernel  one 512-lane workgroup per (view, tile): the tile's 4096 visibility keys live in LDS (32 KiB, no
+//                         device atomics, no clear pass), lane j sets up bin entry j into an LDS record, the 512 lanes share
+//                         the pixels of the records' boxes evenly and resolve visibility with ds_min_u64, then
 //                         every pixel is shaded ONCE, by the triangle that won it (deferred: attributes, LOD and texture are
 //                         not spent on hidden or uncovered pixels, and every lane has a pixel), and leaves as a byte of the
-//                         render -- four pixels per lane, one dword store.
+//                         render -- four pixels side by side per lane and step, one dword store.
 // Visibility key = depth24 << 40 | triangle << 10 | piece << 9 | slot: smaller depth wins, equal depths go to the triangle
 // drawn first (GL_LESS keeps the earlier fragment of glDrawArrays' order) -- deterministic whatever the order of the
 // atomics.  Pixels won through the memory buffer (small triangles, bin overflow) carry slot 0x1FF and set their triangle up
@@ -34,6 +34,7 @@
 // render has no clear pass; tiles without small triangles never touch the buffer.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "nmi_kernels.h"
 
@@ -43,7 +44,8 @@ namespace {
 
 constexpr int kMaxViewsPerLaunch = 64;
 constexpr int kTile = 64;
-constexpr int kBinMax = 512;           // largest bin stride; slots 0 .. 510 are usable
+constexpr int kBinMax = 256;           // largest bin stride; slots 0 .. 254 are usable
+constexpr int kTileThreads = 512;      // 8 wavefronts per tile, two tiles resident per CU (60 KiB of LDS each)
 constexpr uint32_t kNoSlot = 0x1FFu;   // "no LDS record": the pixel was won through the memory buffer
 constexpr int kSmallBox = 16;
 constexpr unsigned long long kEmptyKey = ~0ull;
@@ -52,21 +54,47 @@ struct MeshTexture {
     const float *luma;   // all levels, level l at luma + off[l], row-major, row 0 = v 0
     int levels;
     int w[16], h[16];
+    float inv_w[16], inv_h[16];  // 1 / w, 1 / h (for the wrap)
     long long off[16];
 };
 
-__device__ __forceinline__ float tex_bilinear(const MeshTexture &t, int l, float u, float v)
+// x mod n for an integer-valued x (|x| < 2^24) and 0 < n < 2^24, all in fp32: the quotient estimate may be one off, the
+// two corrections make the result the true remainder in [0, n) -- what an integer modulo (20+ instructions, four per
+// texture sample) would give.
+__device__ __forceinline__ int wrap_index(float x, float n, float inv_n)
 {
-    const int w = t.w[l], h = t.h[l];
-    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    float r = x - floorf(x * inv_n) * n;
+    r = r < 0.0f ? r + n : r;
+    r = r >= n ? r - n : r;
+    return (int)r;
+}
+
+// One level of the pyramid as the sampler wants it: 8 words, kept in LDS by the tile kernel (a per-lane level index into the
+// kernel arguments would be a chain of dependent global loads in front of every texel fetch).
+struct TexLevel {
+    float w, h, inv_w, inv_h;
+    uint32_t wi, hi;
+    uint32_t off_lo, off_hi;  // offset of the level in `luma`, in texels
+};
+
+__device__ __forceinline__ void tex_level_fill(const MeshTexture &t, int l, TexLevel *out)
+{
+    TexLevel L;
+    L.w = (float)t.w[l], L.h = (float)t.h[l], L.inv_w = t.inv_w[l], L.inv_h = t.inv_h[l];
+    L.wi = (uint32_t)t.w[l], L.hi = (uint32_t)t.h[l];
+    L.off_lo = (uint32_t)((unsigned long long)t.off[l] & 0xFFFFFFFFull), L.off_hi = (uint32_t)((unsigned long long)t.off[l] >> 32);
+    *out = L;
+}
+
+__device__ __forceinline__ float tex_bilinear(const float *__restrict__ luma, const TexLevel &L, float u, float v)
+{
+    const float x = u * L.w - 0.5f, y = v * L.h - 0.5f;
     const float xf = floorf(x), yf = floorf(y);
     const float fx = x - xf, fy = y - yf;
-    int i0 = (int)xf % w, j0 = (int)yf % h;  // GL_REPEAT
-    if (i0 < 0) i0 += w;
-    if (j0 < 0) j0 += h;
-    const int i1 = i0 + 1 == w ? 0 : i0 + 1, j1 = j0 + 1 == h ? 0 : j0 + 1;
-    const float *p = t.luma + t.off[l];
-    const float t00 = p[(size_t)j0 * w + i0], t10 = p[(size_t)j0 * w + i1], t01 = p[(size_t)j1 * w + i0], t11 = p[(size_t)j1 * w + i1];
+    const uint32_t i0 = (uint32_t)wrap_index(xf, L.w, L.inv_w), j0 = (uint32_t)wrap_index(yf, L.h, L.inv_h);  // GL_REPEAT
+    const uint32_t i1 = i0 + 1 == L.wi ? 0 : i0 + 1, j1 = j0 + 1 == L.hi ? 0 : j0 + 1;
+    const float *p = luma + (((unsigned long long)L.off_hi << 32) | L.off_lo);
+    const float t00 = p[(size_t)j0 * L.wi + i0], t10 = p[(size_t)j0 * L.wi + i1], t01 = p[(size_t)j1 * L.wi + i0], t11 = p[(size_t)j1 * L.wi + i1];
     const float a = t00 + (t10 - t00) * fx, b = t01 + (t11 - t01) * fx;
     return a + (b - a) * fy;
 }
@@ -232,11 +260,13 @@ __device__ __forceinline__ bool tri_cover(const TriView &t, float fxp, float fyp
     for (int k = 0; k < 3; ++k) {
         const int a = (k + 1) % 3;
         bary[k] = (t.ex[k] * (fyp - t.yw[a]) - t.ey[k] * (fxp - t.xw[a])) * t.inv_area;
-        inside = inside && (bary[k] > 0.0f || (bary[k] == 0.0f && t.own[k]));
+        // bary > 0, or bary == 0 on an edge that owns its pixels: ">= 0" there (true for -0 too, like "== 0").  own[k] is the
+        // same for all lanes of the callers' inner loops, so this is two compares and a scalar select, no per-lane logic.
+        inside = inside & (t.own[k] ? bary[k] >= 0.0f : bary[k] > 0.0f);
     }
     const float z = (bary[0] * t.zw[0] + bary[1] * t.zw[1]) + bary[2] * t.zw[2];
     depth = min((uint32_t)(z * 16777215.0f + 0.5f), 0xFFFFFFu);  // (at z = 1 the fp32 sum rounds up to 2^24: the far plane is the largest depth)
-    return inside && z >= 0.0f && z <= 1.0f;  // (depth clipping; false for NaN)
+    return inside & (z >= 0.0f) & (z <= 1.0f);  // (depth clipping; false for NaN)
 }
 
 // Perspective-correct attributes as three planes over the window: S = u/w, R = v/w, Q = 1/w, each G(x, y) = G0 +
@@ -275,7 +305,8 @@ __device__ __forceinline__ void tri_planes(const TriView &t, const float (&tu)[3
 
 // The fragment shader: uv at the pixel and at its right and upper neighbours (one reciprocal of Q each), level of detail,
 // GL_LINEAR / GL_LINEAR_MIPMAP_LINEAR sample of the luma pyramid -> grey level 0..255.
-__device__ __forceinline__ uint32_t shade_pixel(const Planes &P, const MeshTexture &tex, float fxp, float fyp)
+__device__ __forceinline__ uint32_t shade_pixel(const Planes &P, const float *__restrict__ luma_base, const TexLevel *levels, int n_levels,
+                                            float fxp, float fyp)
 {
     const float dx = fxp - P.xr, dy = fyp - P.yr;
     const float S = (P.s0 + P.sx * dx) + P.sy * dy;
@@ -285,19 +316,21 @@ __device__ __forceinline__ uint32_t shade_pixel(const Planes &P, const MeshTextu
     const float u = S * iq, v = R * iq;
     const float ux = (S + P.sx) * iqx, vx = (R + P.rx) * iqx;
     const float uy = (S + P.sy) * iqy, vy = (R + P.ry) * iqy;
-    const float tw = (float)tex.w[0], th = (float)tex.h[0];
+    const float tw = levels[0].w, th = levels[0].h;
     const float dudx = (ux - u) * tw, dvdx = (vx - v) * th, dudy = (uy - u) * tw, dvdy = (vy - v) * th;
-    const float rho = fmaxf(sqrtf(dudx * dudx + dvdx * dvdx), sqrtf(dudy * dudy + dvdy * dvdy));
-    float luma;
-    const float lambda = log2f(rho);
-    if (!(lambda > 0.0f)) {
-        luma = tex_bilinear(tex, 0, u, v);  // magnification: GL_LINEAR on the base level
-    } else {
-        const float lc = fminf(lambda, (float)(tex.levels - 1));
-        const int l0 = (int)floorf(lc), l1 = min(l0 + 1, tex.levels - 1);
-        const float f = lc - (float)l0;
-        const float s0 = tex_bilinear(tex, l0, u, v), s1 = tex_bilinear(tex, l1, u, v);
-        luma = s0 + (s1 - s0) * f;   // GL_LINEAR_MIPMAP_LINEAR
+    // lambda = log2(rho), rho = the longer of the two footprint axes: log2 of a square root is half the log2 of the square
+    const float rho2 = fmaxf(dudx * dudx + dvdx * dvdx, dudy * dudy + dvdy * dvdy);
+    const float lambda = 0.5f * log2f(rho2);
+    // magnification (lambda <= 0, or NaN): GL_LINEAR on the base level; minification: GL_LINEAR_MIPMAP_LINEAR between levels
+    // floor(lambda) and the next.  One code path: with lambda clamped to 0 the lower level is the base level, and the upper
+    // level is fetched only where it has weight.
+    const float lc = fminf(fmaxf(lambda, 0.0f), (float)(n_levels - 1));
+    const int l0 = (int)floorf(lc), l1 = min(l0 + 1, n_levels - 1);
+    const float f = lc - (float)l0;
+    float luma = tex_bilinear(luma_base, levels[l0], u, v);
+    if (lambda > 0.0f) {
+        const float s1 = tex_bilinear(luma_base, levels[l1], u, v);
+        luma = luma + (s1 - luma) * f;
     }
     return (uint32_t)(fminf(fmaxf(luma, 0.0f), 1.0f) * 255.0f + 0.5f);
 }
@@ -315,6 +348,7 @@ struct BinGrid {
     unsigned long long *zbuf;  // [views][height][width] keys of the direct path, all ones between renders
     int stride, cap;       // entries per bin allocated / usable (cap <= stride, cap <= 511; 0: everything goes the direct way)
     int tiles_x, tiles_y;
+    int dbg;               // profiling ablations (NMI_MESH_DBG, tools only): bit 0 no shading, 1 no visibility sweep, 2 no set-up, 3 no tile work at all
 };
 
 // The direct path: coverage + depth of the triangle's pixels inside [x0, x1] x [y0, y1], visibility by a 64-bit atomicMin in
@@ -338,8 +372,8 @@ __device__ __forceinline__ void raster_direct(const TriView &t, int x0, int x1, 
 // box is small.  A view whose clip planes put all eight corners of that box beyond ONE plane -- by a margin that covers the
 // rounding of both this test and the per-triangle test that follows -- cannot receive anything from the block, which then
 // skips that view's 256 transforms.  The clip tests are affine in the position, so the box test is exact-conservative:
-// results do not change.  On return (after a barrier) beyond[s] != 0 means "skip view s".
-__device__ __forceinline__ void block_frustum_cull(const float *m_all, int views, const float (&lo_in)[3], const float (&hi_in)[3],
+// results do not change.  Views [v_first, v_end) are tested; on return (after a barrier) beyond[s] != 0 means "skip view s".
+__device__ __forceinline__ void block_frustum_cull(const float *m_all, int v_first, int v_end, const float (&lo_in)[3], const float (&hi_in)[3],
                                                    float (*wave_box)[6], uint32_t *beyond)
 {
     float lo[3] = {lo_in[0], lo_in[1], lo_in[2]}, hi[3] = {hi_in[0], hi_in[1], hi_in[2]};
@@ -355,8 +389,8 @@ __device__ __forceinline__ void block_frustum_cull(const float *m_all, int views
         for (int k = 0; k < 3; ++k) wave_box[threadIdx.x >> 6][k] = lo[k], wave_box[threadIdx.x >> 6][3 + k] = hi[k];
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < views * 8; t += blockDim.x) {
-        const int s = t >> 3, c = t & 7;
+    for (int t = threadIdx.x; t < (v_end - v_first) * 8; t += blockDim.x) {
+        const int s = v_first + (t >> 3), c = t & 7;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             lo[k] = fminf(fminf(wave_box[0][k], wave_box[1][k]), fminf(wave_box[2][k], wave_box[3][k]));
@@ -391,30 +425,33 @@ struct ClipItem {
     uint32_t view, pad;
 };
 
-// Appends `id` to bin `b`; the lanes of a wavefront that want the same bin share one counter update.  `want` < 0: this lane
+// Appends `id` to bin `want`; the lanes of a wavefront that want the same bin share one counter update, and the updates of
+// the different bins of a call are ONE atomic instruction (their latencies overlap: a wavefront of neighbouring triangles
+// touches ~8 bins per view, and 8 dependent device atomics per view was most of this kernel's time).  `want` < 0: this lane
 // has nothing to append (it still takes part).  Returns the slot, or -1 when the bin is full.
 __device__ __forceinline__ int bin_append(const BinGrid &g, int want, uint32_t id)
 {
-    int slot = -1;
-    unsigned long long todo = __ballot(want >= 0);
     const int lane = (int)(threadIdx.x & 63);
-    while (todo) {  // wavefront-uniform
-        const int leader = __builtin_ctzll(todo);
-        const int b = __shfl(want, leader, 64);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // group the lanes by bin: leader = lowest lane of the group, rank = position in it, size = lanes in it
+    int leader = lane;
+    uint32_t rank = 0, size = 1;
+    unsigned long long todo = __ballot(want >= 0);
+    while (todo) {  // wavefront-uniform, one round per distinct bin, no memory access
+        const int first = __builtin_ctzll(todo);
+        const int b = __shfl(want, first, 64);
         const unsigned long long same = __ballot(want == b);
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&g.state[2 * (size_t)b], (uint32_t)__popcll(same));
-        base = (uint32_t)__shfl((int)base, leader, 64);
-        if (want == b) {
-            const uint32_t at = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-            if (at < (uint32_t)g.cap) {
-                g.bins[(size_t)b * g.stride + at] = id;
-                slot = (int)at;
-            }
-        }
+        if (want == b) leader = first, rank = (uint32_t)__popcll(same & below), size = (uint32_t)__popcll(same);
         todo &= ~same;
     }
-    return slot;
+    uint32_t base = 0;
+    if (want >= 0 && lane == leader) base = atomicAdd(&g.state[2 * (size_t)want], size);
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    if (want < 0) return -1;
+    const uint32_t at = base + rank;
+    if (at >= (uint32_t)g.cap) return -1;
+    g.bins[(size_t)want * g.stride + at] = id;
+    return (int)at;
 }
 
 }  // namespace
@@ -427,8 +464,12 @@ __global__ __launch_bounds__(256) void nmi_mesh_bin_kernel(const float *__restri
     __shared__ float m_all[kMaxViewsPerLaunch * 16];
     __shared__ float wave_box[4][6];
     __shared__ uint32_t beyond[kMaxViewsPerLaunch];
-    for (int t = threadIdx.x; t < views * 16; t += blockDim.x) m_all[t] = mvps[t];
-    for (int t = threadIdx.x; t < views; t += blockDim.x) beyond[t] = 0x3Fu;
+    // blockIdx.y: which share of the views this block takes its 256 triangles through.  Few triangles -> many shares
+    // (4,800 triangles x 27 views: a lane per pair), so that the kernel is not 19 workgroups each walking 27 views through
+    // dependent atomics; many triangles -> one share, the mesh is read once.
+    const int v_first = (int)(((long long)views * blockIdx.y) / gridDim.y), v_end = (int)(((long long)views * (blockIdx.y + 1)) / gridDim.y);
+    for (int t = threadIdx.x + v_first * 16; t < v_end * 16; t += blockDim.x) m_all[t] = mvps[t];
+    for (int t = threadIdx.x; t < views; t += blockDim.x) beyond[t] = (t >= v_first && t < v_end) ? 0x3Fu : 0u;
     const long long tri = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     const bool valid = tri < ntri;
     float px[3] = {0, 0, 0}, py[3] = {0, 0, 0}, pz[3] = {0, 0, 0}, tu[3], tv[3];
@@ -441,10 +482,10 @@ __global__ __launch_bounds__(256) void nmi_mesh_bin_kernel(const float *__restri
                              valid ? fminf(pz[0], fminf(pz[1], pz[2])) : inf};
         const float hi[3] = {valid ? fmaxf(px[0], fmaxf(px[1], px[2])) : -inf, valid ? fmaxf(py[0], fmaxf(py[1], py[2])) : -inf,
                              valid ? fmaxf(pz[0], fmaxf(pz[1], pz[2])) : -inf};
-        block_frustum_cull(m_all, views, lo, hi, wave_box, beyond);
+        block_frustum_cull(m_all, v_first, v_end, lo, hi, wave_box, beyond);
     }
     const int tiles = g.tiles_x * g.tiles_y;
-    for (int s = 0; s < views; ++s) {
+    for (int s = v_first; s < v_end; ++s) {
         if (beyond[s]) continue;  // block-uniform
         TriView t;
         bool large = false;
@@ -541,22 +582,26 @@ namespace {
 // LDS record of one bin entry (words).
 enum : int {
     R_XW = 0, R_YW = 3, R_ZW = 6, R_INV_AREA = 9,
-    R_PLANES = 10,  // xr, yr, s0, sx, sy, r0, rx, ry, q0, qx, qy
-    R_OWN = 21,     // bits 0..2: edge k owns the pixels on it
-    R_BOX_X = 22,   // x0 | x1 << 16: the triangle's pixel box inside this tile
-    R_BOX_Y = 23,
-    R_ID = 24,      // triangle << 1 | piece
-    R_STAMP = 25,   // log2 of the stamp's width | stamps per row << 8 | stamps << 16
-    R_FIRST = 26,   // stamps of the records before this one
+    R_OWN = 10,     // bits 0..2: edge k owns the pixels on it
+    R_BOX = 11,     // x0 | y0 << 16: first pixel of the triangle's pixel box inside this tile
+    R_BOX_W = 12,   // the box's width | its pixels << 16
+    R_FIRST = 13,   // box pixels of the records before this one
+    R_ID = 14,      // triangle << 1 | piece
+    R_PLANES = 16,  // xr, yr, s0, sx, sy, r0, rx, ry, q0, qx, qy
     R_WORDS = 28,
 };
 
 struct TileLds {
     unsigned long long keys[kTile * kTile];
     uint32_t rec[kBinMax][R_WORDS];
-    uint32_t wave_sum[16];
+    uint32_t wave_sum[kTileThreads / 64];
     uint32_t hdr[4];
+    TexLevel tex[16];
 };
+
+// Where the key of tile pixel (x, y) lives: row y, rotated by 8 keys per row (a multiple of 4: a lane's four neighbouring
+// output pixels stay neighbours).
+__device__ __forceinline__ int key_index(int x, int y) { return y * kTile + ((x + 8 * y) & (kTile - 1)); }
 
 __device__ __forceinline__ void planes_from_lds(const uint32_t *r, Planes &P)
 {
@@ -566,11 +611,12 @@ __device__ __forceinline__ void planes_from_lds(const uint32_t *r, Planes &P)
 
 }  // namespace
 
-__global__ __launch_bounds__(1024) void nmi_mesh_tile_kernel(const float *__restrict__ xyz, const float *__restrict__ uv,
-                                                             const float *__restrict__ mvps, uint8_t *__restrict__ out, int width, int height,
-                                                             MeshTexture tex, BinGrid g)
+__global__ __launch_bounds__(kTileThreads) void nmi_mesh_tile_kernel(const float *__restrict__ xyz, const float *__restrict__ uv,
+                                                                     const float *__restrict__ mvps, uint8_t *__restrict__ out, int width,
+                                                                     int height, MeshTexture tex, BinGrid g)
 {
     __shared__ TileLds lds;
+    constexpr int kWaves = kTileThreads / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = g.tiles_x * g.tiles_y;
     const int bin = blockIdx.x;
@@ -583,16 +629,20 @@ __global__ __launch_bounds__(1024) void nmi_mesh_tile_kernel(const float *__rest
         lds.hdr[0] = c < (uint32_t)g.cap ? c : (uint32_t)g.cap;
         lds.hdr[1] = f;
     }
+    if (tid >= 64 && tid < 64 + tex.levels) tex_level_fill(tex, tid - 64, &lds.tex[tid - 64]);
     __syncthreads();
     const int n = (int)lds.hdr[0];
     const bool from_memory = lds.hdr[1] != 0u;
-    // this lane's four output pixels
+    // this lane's output pixels: four in a row, in rows oy and oy + 32
     const int ox = X0 + (tid & 15) * 4, oy = Y0 + (tid >> 4);
-    uint8_t *dst = out + ((size_t)s * height + oy) * width + ox;
-    const bool row_ok = oy < height && ox < width;
+    const bool col_ok = ox < width;
     const bool dword_ok = ox + 3 < width && ((width & 3) == 0) && (((uintptr_t)out & 3) == 0);
-    if (n == 0 && !from_memory) {  // nothing was drawn into this tile: background (glClearColor(1,1,1), rendering.hpp:533)
-        if (row_ok) {
+    if ((n == 0 && !from_memory) || (g.dbg & 8)) {  // nothing was drawn into this tile: background (glClearColor(1,1,1), rendering.hpp:533)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int y = oy + 32 * half;
+            if (!col_ok || y >= height) continue;
+            uint8_t *dst = out + ((size_t)s * height + y) * width + ox;
             if (dword_ok)
                 *reinterpret_cast<uint32_t *>(dst) = 0xFFFFFFFFu;
             else
@@ -600,12 +650,11 @@ __global__ __launch_bounds__(1024) void nmi_mesh_tile_kernel(const float *__rest
         }
         return;
     }
-    unsigned long long keys[4] = {kEmptyKey, kEmptyKey, kEmptyKey, kEmptyKey};
     if (n > 0) {
-        for (int i = tid; i < kTile * kTile; i += 1024) lds.keys[i] = kEmptyKey;
+        for (int i = tid; i < kTile * kTile; i += kTileThreads) lds.keys[i] = kEmptyKey;
         // ---- set-up: lane j turns bin entry j into a record ------------------------------------------------------------
         uint32_t nst = 0;
-        if (tid < n) {
+        if (tid < n && !(g.dbg & 4)) {
             const uint32_t id = g.bins[(size_t)bin * g.stride + tid];
             uint32_t *r = lds.rec[tid];
             TriView t;
@@ -616,7 +665,6 @@ __global__ __launch_bounds__(1024) void nmi_mesh_tile_kernel(const float *__rest
                 bx0 = max(t.x_lo, X0), bx1 = min(t.x_hi, X0 + kTile - 1), by0 = max(t.y_lo, Y0), by1 = min(t.y_hi, Y0 + kTile - 1);
                 ok = bx0 <= bx1 && by0 <= by1;
             }
-            uint32_t stamp = 0;
             if (ok) {
                 Planes P;
                 tri_planes(t, su, sv, P);
@@ -628,25 +676,15 @@ __global__ __launch_bounds__(1024) void nmi_mesh_tile_kernel(const float *__rest
                 f[R_PLANES + 5] = P.r0, f[R_PLANES + 6] = P.rx, f[R_PLANES + 7] = P.ry, f[R_PLANES + 8] = P.q0, f[R_PLANES + 9] = P.qx;
                 f[R_PLANES + 10] = P.qy;
                 r[R_OWN] = (t.own[0] ? 1u : 0u) | (t.own[1] ? 2u : 0u) | (t.own[2] ? 4u : 0u);
-                r[R_BOX_X] = (uint32_t)bx0 | ((uint32_t)bx1 << 16);
-                r[R_BOX_Y] = (uint32_t)by0 | ((uint32_t)by1 << 16);
-                // the 64 lanes of a wavefront form a stamp of (1 << lw) x (64 >> lw) pixels: the shape that covers this box in the fewest steps
-                const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
-                int best = 1 << 30, best_lw = 3, best_nsx = 1;
-                const int order[7] = {3, 4, 2, 5, 1, 6, 0};
-#pragma unroll
-                for (int q = 0; q < 7; ++q) {
-                    const int lw = order[q], sw = 1 << lw, sh = 64 >> lw;
-                    const int nsx = (bw + sw - 1) >> lw, nsy = (bh + sh - 1) / sh;
-                    if (nsx * nsy < best) best = nsx * nsy, best_lw = lw, best_nsx = nsx;
-                }
-                nst = (uint32_t)best;
-                stamp = (uint32_t)best_lw | ((uint32_t)best_nsx << 8) | (nst << 16);
+                r[R_BOX] = (uint32_t)bx0 | ((uint32_t)by0 << 16);
+                nst = (uint32_t)((bx1 - bx0 + 1) * (by1 - by0 + 1));  // at most 4096
+                r[R_BOX_W] = (uint32_t)(bx1 - bx0 + 1) | (nst << 16);
+            } else {
+                r[R_BOX_W] = 0u;
             }
             r[R_ID] = id;
-            r[R_STAMP] = stamp;
         }
-        // stamps of the records before each one (n <= 512: wavefronts 0..7 hold them)
+        // stamps of the records before each one (n <= 255: wavefronts 0..3 hold them)
         uint32_t incl = nst;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -657,109 +695,152 @@ __global__ __launch_bounds__(1024) void nmi_mesh_tile_kernel(const float *__rest
         __syncthreads();
         uint32_t before = 0, total = 0;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) {
+        for (int w = 0; w < kBinMax / 64; ++w) {
             const uint32_t ws = lds.wave_sum[w];
             before += w < wave ? ws : 0u;
             total += ws;
         }
         if (tid < n) lds.rec[tid][R_FIRST] = before + incl - nst;
         __syncthreads();
-        // ---- visibility: the wavefronts share the stamps evenly ---------------------------------------------------------
-        uint32_t gpos = (uint32_t)(((unsigned long long)total * (unsigned)wave) >> 4), gend = (uint32_t)(((unsigned long long)total * (unsigned)(wave + 1)) >> 4);
-        if (gpos < gend) {
-            int lo = 0, hi = n - 1;  // the last record that starts at or before gpos (records without stamps share their successor's start)
+        // ---- visibility -------------------------------------------------------------------------------------------------------
+        // The pixel boxes of all records, one after the other, form one long list of (record, pixel) pairs; every lane takes an
+        // equal, contiguous share of it and walks it alone: its record's corners in its own registers (reloaded when the share
+        // runs into the next record), coverage + depth per pixel, ds_min_u64 on the pixel's key.  All 512 lanes have a pixel in
+        // every step whatever the triangles' sizes -- 64-pixel stamps laid over each box, a wavefront per record, had 20-40 %
+        // of their lanes inside the box for the 9 x 9-pixel boxes of a 120 k-triangle mesh and ran 3 steps per record.
+        const uint32_t per = (total + kTileThreads - 1) / kTileThreads;
+        uint32_t p = (uint32_t)tid * per;
+        const uint32_t pend = min(total, p + per);
+        if (p < pend && !(g.dbg & 6)) {
+            int lo = 0, hi = n - 1;  // the last record that starts at or before p (records without pixels share their successor's start)
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
-                if (lds.rec[mid][R_FIRST] <= gpos)
+                if (lds.rec[mid][R_FIRST] <= p)
                     lo = mid;
                 else
                     hi = mid - 1;
             }
-            int i = lo;
-            while (gpos < gend) {  // wavefront-uniform
-                const uint32_t *r = lds.rec[i];
-                const uint32_t stamp = r[R_STAMP], first = r[R_FIRST], nsti = stamp >> 16;
-                if (gpos >= first + nsti) {  // (cannot happen for a record found by the search; later ones may be empty)
+            int i = lo - 1;
+            TriView t;
+            uint32_t own = 0, left = 0;       // pixels of the current record still to visit (0: load the next record first)
+            int xx = 0, yy = 0, x_first = 0, x_last = 0;
+            unsigned long long key_lo = 0;
+            while (p < pend) {
+                if (left == 0) {
                     ++i;
-                    continue;
-                }
-                const float *f = reinterpret_cast<const float *>(r);
-                TriView t;
+                    const uint32_t *r = lds.rec[i];
+                    const uint32_t bw_n = r[R_BOX_W], first = r[R_FIRST], npx = bw_n >> 16;
+                    if (p >= first + npx) continue;  // (a record without pixels)
+                    const float *f = reinterpret_cast<const float *>(r);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) t.xw[k] = f[R_XW + k], t.yw[k] = f[R_YW + k], t.zw[k] = f[R_ZW + k];
-                t.inv_area = f[R_INV_AREA];
-                const uint32_t own = r[R_OWN];
+                    for (int k = 0; k < 3; ++k) t.xw[k] = f[R_XW + k], t.yw[k] = f[R_YW + k], t.zw[k] = f[R_ZW + k];
+                    t.inv_area = f[R_INV_AREA];
+                    own = r[R_OWN];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int a = (k + 1) % 3, b = (k + 2) % 3;
+                        t.ex[k] = t.xw[b] - t.xw[a];
+                        t.ey[k] = t.yw[b] - t.yw[a];
+                    }
+                    const uint32_t bw = bw_n & 0xFFFFu, local = p - first;
+                    const uint32_t row = local / bw;
+                    x_first = (int)(r[R_BOX] & 0xFFFFu);
+                    x_last = x_first + (int)bw - 1;
+                    xx = x_first + (int)(local - row * bw);
+                    yy = (int)(r[R_BOX] >> 16) + (int)row;
+                    left = min(npx - local, pend - p);
+                    key_lo = ((unsigned long long)r[R_ID] << 9) | (unsigned long long)(uint32_t)i;
+                }
+                // coverage (top-left rule) and depth of pixel (xx, yy): tri_cover with per-lane ownership bits
+                const float fxp = (float)xx + 0.5f, fyp = (float)yy + 0.5f;
+                float bary[3];
+                uint32_t in = 1u;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const int a = (k + 1) % 3, b = (k + 2) % 3;
-                    t.ex[k] = t.xw[b] - t.xw[a];
-                    t.ey[k] = t.yw[b] - t.yw[a];
-                    t.own[k] = (own >> k) & 1u;
+                    const int a = (k + 1) % 3;
+                    bary[k] = (t.ex[k] * (fyp - t.yw[a]) - t.ey[k] * (fxp - t.xw[a])) * t.inv_area;
+                    in &= (uint32_t)(bary[k] > 0.0f) | ((uint32_t)(bary[k] == 0.0f) & (own >> k));
                 }
-                const int bx0 = (int)(r[R_BOX_X] & 0xFFFFu), bx1 = (int)(r[R_BOX_X] >> 16), by0 = (int)(r[R_BOX_Y] & 0xFFFFu), by1 = (int)(r[R_BOX_Y] >> 16);
-                const int lw = (int)(stamp & 7u), nsx = (int)((stamp >> 8) & 0xFFu);
-                const int lx = lane & ((1 << lw) - 1), ly = lane >> lw, sh = 64 >> lw;
-                const unsigned long long id = r[R_ID];
-                uint32_t q = gpos - first;
-                const uint32_t qend = min(nsti, q + (gend - gpos));
-                gpos += qend - q;
-                int qx = (int)(q % (uint32_t)nsx), qy = (int)(q / (uint32_t)nsx);
-                for (; q < qend; ++q) {
-                    const int xx = bx0 + (qx << lw) + lx, yy = by0 + qy * sh + ly;
-                    uint32_t depth;
-                    if (xx <= bx1 && yy <= by1 && tri_cover(t, (float)xx + 0.5f, (float)yy + 0.5f, depth))
-                        (void)__hip_atomic_fetch_min(&lds.keys[(yy - Y0) * kTile + (xx - X0)], make_key(depth, id, (uint32_t)i), __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (++qx == nsx) qx = 0, ++qy;
+                const float z = (bary[0] * t.zw[0] + bary[1] * t.zw[1]) + bary[2] * t.zw[2];
+                if ((in & (uint32_t)(z >= 0.0f) & (uint32_t)(z <= 1.0f)) != 0u && !(g.dbg & 16)) {
+                    const uint32_t depth = min((uint32_t)(z * 16777215.0f + 0.5f), 0xFFFFFFu);
+                    (void)__hip_atomic_fetch_min(&lds.keys[key_index(xx - X0, yy - Y0)], ((unsigned long long)depth << 40) | key_lo, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                ++i;
+                ++p;
+                --left;
+                if (xx == x_last)
+                    xx = x_first, ++yy;
+                else
+                    ++xx;
             }
         }
         __syncthreads();
-        const ulonglong2 *k2 = reinterpret_cast<const ulonglong2 *>(&lds.keys[(tid >> 4) * kTile + (tid & 15) * 4]);
-        const ulonglong2 a = k2[0], b = k2[1];
-        keys[0] = a.x, keys[1] = a.y, keys[2] = b.x, keys[3] = b.y;
     }
-    if (!row_ok) return;
-    // ---- what came through the memory buffer (small triangles, bin overflow): take it and leave the buffer clean ---------
-    if (from_memory) {
-        unsigned long long *zp = g.zbuf + ((size_t)s * height + oy) * width + ox;
-        for (int k = 0; k < 4 && ox + k < width; ++k) {
-            const unsigned long long z = zp[k];
-            if (z != kEmptyKey) {
-                zp[k] = kEmptyKey;
-                keys[k] = keys[k] < z ? keys[k] : z;
+    if (!col_ok) return;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const int y = oy + 32 * half;
+        if (y >= height) break;
+        unsigned long long keys[4] = {kEmptyKey, kEmptyKey, kEmptyKey, kEmptyKey};
+        if (n > 0) {
+            const ulonglong2 *k2 = reinterpret_cast<const ulonglong2 *>(&lds.keys[key_index((tid & 15) * 4, y - Y0)]);
+            const ulonglong2 a = k2[0], b = k2[1];
+            keys[0] = a.x, keys[1] = a.y, keys[2] = b.x, keys[3] = b.y;
+        }
+        // ---- what came through the memory buffer (small triangles, bin overflow): take it and leave the buffer clean -----
+        if (from_memory) {
+            unsigned long long *zp = g.zbuf + ((size_t)s * height + y) * width + ox;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (ox + k >= width) break;
+                const unsigned long long z = zp[k];
+                if (z != kEmptyKey) {
+                    zp[k] = kEmptyKey;
+                    keys[k] = keys[k] < z ? keys[k] : z;
+                }
             }
         }
-    }
-    // ---- shade every pixel once, by the triangle that won it --------------------------------------------------------------
-    uint32_t packed = 0;
+        // ---- shade every pixel once, by the triangle that won it ------------------------------------------------------------
+        uint32_t packed = 0xFFFFFFFFu;
+        // Pixels won through the memory buffer have no record in LDS: their triangle is set up here, on the fly.  One copy of
+        // that code, outside the unrolled loop below (for a mesh of pixel-sized triangles this IS the shading loop).
+        if (from_memory) {
 #pragma unroll 1
-    for (int k = 0; k < 4; ++k) {
-        uint32_t grey = 255u;
-        const unsigned long long key = keys[k];
-        if (key != kEmptyKey && ox + k < width) {
-            const uint32_t slot = (uint32_t)(key & 0x1FFu);
-            const float fxp = (float)(ox + k) + 0.5f, fyp = (float)oy + 0.5f;
-            Planes P;
-            bool ok = true;
-            if (slot != kNoSlot) {
-                planes_from_lds(lds.rec[slot], P);
-            } else {
+            for (int k = 0; k < 4; ++k) {
+                const unsigned long long key = keys[0];  // (the keys rotate through slot 0: no dynamic register indexing)
+                keys[0] = keys[1], keys[1] = keys[2], keys[2] = keys[3], keys[3] = key;
+                if (key == kEmptyKey || (uint32_t)(key & 0x1FFu) != kNoSlot || ox + k >= width) continue;
                 TriView t;
                 float su[3], sv[3];
                 const unsigned long long id = (key >> 9) & 0x7FFFFFFFull;
-                ok = setup_piece(xyz, uv, (long long)(id >> 1), (int)(id & 1ull), mvps + s * 16, width, height, t, su, sv);  // (true: it produced this key)
-                if (ok) tri_planes(t, su, sv, P);
+                uint32_t grey = 255u;
+                if (setup_piece(xyz, uv, (long long)(id >> 1), (int)(id & 1ull), mvps + s * 16, width, height, t, su, sv)) {  // (true: it produced this key)
+                    Planes P;
+                    tri_planes(t, su, sv, P);
+                    grey = shade_pixel(P, tex.luma, lds.tex, tex.levels, (float)(ox + k) + 0.5f, (float)y + 0.5f);
+                }
+                packed = (packed & ~(0xFFu << (8 * k))) | (grey << (8 * k));
+                keys[3] = kEmptyKey;  // done
             }
-            if (ok) grey = shade_pixel(P, tex, fxp, fyp);
         }
-        packed |= grey << (8 * k);
+        // the four pixels side by side: their texel fetches overlap
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long key = keys[k];
+            if (key != kEmptyKey && ox + k < width && !(g.dbg & 1)) {
+                Planes P;
+                planes_from_lds(lds.rec[(uint32_t)(key & 0x1FFu)], P);
+                const uint32_t grey = shade_pixel(P, tex.luma, lds.tex, tex.levels, (float)(ox + k) + 0.5f, (float)y + 0.5f);
+                packed = (packed & ~(0xFFu << (8 * k))) | (grey << (8 * k));
+            }
+        }
+        uint8_t *dst = out + ((size_t)s * height + y) * width + ox;
+        if (dword_ok)
+            *reinterpret_cast<uint32_t *>(dst) = packed;
+        else
+            for (int k = 0; k < 4 && ox + k < width; ++k) dst[k] = (uint8_t)(packed >> (8 * k));
     }
-    if (dword_ok)
-        *reinterpret_cast<uint32_t *>(dst) = packed;
-    else
-        for (int k = 0; k < 4 && ox + k < width; ++k) dst[k] = (uint8_t)(packed >> (8 * k));
 }
 
 __global__ __launch_bounds__(256) void nmi_mesh_clear_kernel(unsigned long long *zbuf, size_t n, uint32_t *state, size_t n_state)
@@ -773,7 +854,7 @@ void mesh_geometry(int S, int width, int height, int *tiles_x, int *tiles_y, int
 {
     *tiles_x = (width + kTile - 1) / kTile;
     *tiles_y = (height + kTile - 1) / kTile;
-    // bins share a budget of 32 MiB: 512 entries each for 27 views of 848x480 (6 MiB), fewer for very large frames
+    // bins share a budget of 32 MiB: 256 entries each for 27 views of 848x480 (3 MiB), fewer for very large frames
     const long long bins = (long long)(S > 0 ? S : 1) * *tiles_x * *tiles_y;
     int st = kBinMax;
     while (st > 32 && bins * st * 4 > (32ll << 20)) st >>= 1;
@@ -815,8 +896,11 @@ hipError_t launch_render_mesh(const float *xyz, const float *uv, long long ntri,
     MeshTexture tex{};
     tex.luma = luma;
     tex.levels = levels;
-    for (int l = 0; l < levels && l < 16; ++l) tex.w[l] = lw[l], tex.h[l] = lh[l], tex.off[l] = loff[l];
+    for (int l = 0; l < levels && l < 16; ++l)
+        tex.w[l] = lw[l], tex.h[l] = lh[l], tex.off[l] = loff[l], tex.inv_w[l] = 1.0f / (float)lw[l], tex.inv_h[l] = 1.0f / (float)lh[l];
     BinGrid g{};
+    static const int dbg = getenv("NMI_MESH_DBG") ? atoi(getenv("NMI_MESH_DBG")) : 0;
+    g.dbg = dbg;
     mesh_geometry(layout_views, width, height, &g.tiles_x, &g.tiles_y, &g.stride);  // the layout the work area was allocated for
     g.cap = g.stride - 1 < bin_cap_limit ? g.stride - 1 : bin_cap_limit;
     if (g.cap < 0) g.cap = 0;
@@ -831,12 +915,15 @@ hipError_t launch_render_mesh(const float *xyz, const float *uv, long long ntri,
             const hipError_t e = hipMemsetAsync(w.clip_state, 0, 2 * sizeof(unsigned long long), stream);
             if (e != hipSuccess) return e;
             ClipItem *clipq = static_cast<ClipItem *>(w.clip_queue);
-            hipLaunchKernelGGL(nmi_mesh_bin_kernel, dim3((unsigned)((ntri + 255) / 256)), dim3(256), 0, stream, xyz, uv, ntri,
+            // shares of the views: aim at ~half a million lanes
+            long long shares = (500000 + ntri - 1) / ntri;
+            shares = shares < 1 ? 1 : (shares > views ? views : shares);
+            hipLaunchKernelGGL(nmi_mesh_bin_kernel, dim3((unsigned)((ntri + 255) / 256), (unsigned)shares), dim3(256), 0, stream, xyz, uv, ntri,
                                mvps + (size_t)s0 * 16, views, width, height, g, clipq, w.clip_state, clip_cap);
-            hipLaunchKernelGGL(nmi_mesh_clip_kernel, dim3(512), dim3(256), 0, stream, xyz, uv, ntri, mvps + (size_t)s0 * 16, views, width,
+            hipLaunchKernelGGL(nmi_mesh_clip_kernel, dim3(64), dim3(256), 0, stream,  // (crossing triangles are few; an empty pass should cost little) xyz, uv, ntri, mvps + (size_t)s0 * 16, views, width,
                                height, g, clipq, w.clip_state, clip_cap);
         }
-        hipLaunchKernelGGL(nmi_mesh_tile_kernel, dim3((unsigned)(views * tiles)), dim3(1024), 0, stream, xyz, uv, mvps + (size_t)s0 * 16,
+        hipLaunchKernelGGL(nmi_mesh_tile_kernel, dim3((unsigned)(views * tiles)), dim3(kTileThreads), 0, stream, xyz, uv, mvps + (size_t)s0 * 16,
                            out + (size_t)s0 * width * height, width, height, tex, g);
     }
     return hipGetLastError();
