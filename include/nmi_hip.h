@@ -201,7 +201,8 @@ int nmi_render_points(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int6
  *                       (objloader.cpp:140-224); h_mvps as for nmi_render_points; output uint8 [S][H][W], bottom-up rows,
  *                       background 255.  Back faces culled (counter-clockwise front), depth test LESS, GL_REPEAT,
  *                       GL_LINEAR / GL_LINEAR_MIPMAP_LINEAR.  Triangles are clipped against the near plane in clip space
- *                       (a ground plane passing under the camera keeps its visible part).
+ *                       (a ground plane passing under the camera keeps its visible part).  Among fragments of equal 24-bit
+ *                       depth the triangle drawn first (lowest index) wins, as GL_LESS leaves it.  At most 2^30 - 1 triangles.
  * Enqueued on the context's stream.  Parity with an OpenGL driver is unpinned (kernel comment).
  */
 typedef struct nmi_texture nmi_texture;
@@ -349,9 +350,9 @@ int nmi_last_kernel_ms(nmi_ctx *ctx, float *h_ms);
                                   and the call polls it (default), 0 hipMemcpyAsync + hipStreamSynchronize */
 #define NMI_OPT_XCD_TILING 5   /* 1 (default): candidates are visited in (warp x render) tiles so that the 32 workgroups
                                   of one XCD share ~12 images in its L2; 0: linear order.  Same results either way. */
-#define NMI_OPT_TILE_QUEUE 6   /* mesh renderer: capacity (work items) of the queue that hands large triangles to the
-                                  tile pass, at most 4194304 (default); 0 = every triangle is shaded by its own lane.
-                                  Same image for every value (small values exercise the overflow path in tests). */
+#define NMI_OPT_TILE_QUEUE 6   /* mesh renderer: usable entries of each screen-tile bin (at most 255, the default; the value is
+                                  clamped).  A triangle that finds a bin full is rasterised by its own lane instead; 0 = every
+                                  triangle is.  Same image for every value (small values exercise the overflow path in tests). */
 #define NMI_OPT_CLIP_QUEUE 11  /* mesh renderer: capacity of the queue that hands (triangle, view) pairs crossing the near plane to
                                   the clipping pass, at most 262144 (default).  With more such pairs than that the clipping
                                   pass finds them again itself; same image for every value (0 exercises that path in tests). */

@@ -561,7 +561,16 @@ __global__ __launch_bounds__(256) void nmi_mesh_clip_kernel(const float *__restr
                                                             const ClipItem *__restrict__ clipq, unsigned long long *__restrict__ clip_state,
                                                             unsigned long long clip_cap)
 {
-    const unsigned long long claimed = clip_state[0];
+    __shared__ unsigned long long claimed_s;
+    if (threadIdx.x == 0) claimed_s = __hip_atomic_load(&clip_state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned long long claimed = claimed_s;
+    // The last block to have read the count zeroes it for the next render (no memset node in a level's graph): every block
+    // draws its ticket after its read.
+    if (threadIdx.x == 0 && atomicAdd(&clip_state[1], 1ull) == gridDim.x - 1) {
+        __hip_atomic_store(&clip_state[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&clip_state[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const unsigned long long gid = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x, stride = (unsigned long long)gridDim.x * blockDim.x;
     if (claimed <= clip_cap) {
         for (unsigned long long i = gid; i < claimed; i += stride)
@@ -843,9 +852,11 @@ __global__ __launch_bounds__(kTileThreads) void nmi_mesh_tile_kernel(const float
     }
 }
 
-__global__ __launch_bounds__(256) void nmi_mesh_clear_kernel(unsigned long long *zbuf, size_t n, uint32_t *state, size_t n_state)
+__global__ __launch_bounds__(256) void nmi_mesh_clear_kernel(unsigned long long *zbuf, size_t n, uint32_t *state, size_t n_state,
+                                                             unsigned long long *clip_state)
 {
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    if (t < 2) clip_state[t] = 0ull;
     for (size_t i = t; i < n; i += step) zbuf[i] = kEmptyKey;
     for (size_t i = t; i < n_state; i += step) state[i] = 0u;
 }
@@ -882,7 +893,7 @@ size_t mesh_clip_item_bytes() { return sizeof(ClipItem); }
 hipError_t launch_mesh_clear(const MeshWork &w, int S, int width, int height, hipStream_t stream)
 {
     const size_t n = (size_t)S * width * height, ns = mesh_state_bytes(S, width, height) / sizeof(uint32_t);
-    hipLaunchKernelGGL(nmi_mesh_clear_kernel, dim3(4096), dim3(256), 0, stream, w.zbuf, n, w.state, ns);
+    hipLaunchKernelGGL(nmi_mesh_clear_kernel, dim3(4096), dim3(256), 0, stream, w.zbuf, n, w.state, ns, w.clip_state);
     return hipGetLastError();
 }
 
@@ -912,15 +923,14 @@ hipError_t launch_render_mesh(const float *xyz, const float *uv, long long ntri,
         g.state = w.state + (size_t)s0 * tiles * 2;
         g.zbuf = w.zbuf + (size_t)s0 * width * height;
         if (ntri > 0) {
-            const hipError_t e = hipMemsetAsync(w.clip_state, 0, 2 * sizeof(unsigned long long), stream);
-            if (e != hipSuccess) return e;
             ClipItem *clipq = static_cast<ClipItem *>(w.clip_queue);
             // shares of the views: aim at ~half a million lanes
             long long shares = (500000 + ntri - 1) / ntri;
             shares = shares < 1 ? 1 : (shares > views ? views : shares);
             hipLaunchKernelGGL(nmi_mesh_bin_kernel, dim3((unsigned)((ntri + 255) / 256), (unsigned)shares), dim3(256), 0, stream, xyz, uv, ntri,
                                mvps + (size_t)s0 * 16, views, width, height, g, clipq, w.clip_state, clip_cap);
-            hipLaunchKernelGGL(nmi_mesh_clip_kernel, dim3(64), dim3(256), 0, stream,  // (crossing triangles are few; an empty pass should cost little) xyz, uv, ntri, mvps + (size_t)s0 * 16, views, width,
+            // (crossing triangles are few: an empty pass should cost little)
+            hipLaunchKernelGGL(nmi_mesh_clip_kernel, dim3(64), dim3(256), 0, stream, xyz, uv, ntri, mvps + (size_t)s0 * 16, views, width,
                                height, g, clipq, w.clip_state, clip_cap);
         }
         hipLaunchKernelGGL(nmi_mesh_tile_kernel, dim3((unsigned)(views * tiles)), dim3(kTileThreads), 0, stream, xyz, uv, mvps + (size_t)s0 * 16,

@@ -367,6 +367,57 @@ def test_gpu_mesh_large_triangles_and_queue_overflow():
     assert diff.max() <= 1 and (diff != 0).mean() < 2e-3, (diff.max(), (diff != 0).mean())
 
 
+def _coplanar_scene(w, h):
+    """Two copies of a textured plane at the SAME depth with different uv (so every pixel is an exact depth tie between two
+    triangles), the second copy cut into many small triangles: ties between large (binned) and small (per-lane) triangles."""
+    xa, ua, rgb, rp = plane_mesh(w, h, nx=3, ny=2)
+    xa, ua = xa[:3 * 2 * 3 * 2], ua[:3 * 2 * 3 * 2]                    # the plane only (no occluder / back-facer)
+    xb, ub, _, _ = plane_mesh(w, h, nx=60, ny=44)
+    xb, ub = xb[:3 * 2 * 60 * 44], ub[:3 * 2 * 60 * 44]
+    ub = (ub + np.float32(0.37)).astype(np.float32)                    # another part of the texture
+    return xa, ua, xb, ub, rgb, rp
+
+
+def test_mesh_twin_equal_depth_goes_to_the_triangle_drawn_first():
+    w, h = 96, 72
+    xa, ua, xb, ub, rgb, rp = _coplanar_scene(w, h)
+    lv = mo.mip_luma(rgb)
+    m = capi.render_mvp(rp, (0, 0, 0), (0, 0, 1), (0, -1, 0), (0, 0, 0))
+    only_a, only_b = mo.render_mesh(xa, ua, lv, m, w, h), mo.render_mesh(xb, ub, lv, m, w, h)
+    ab = mo.render_mesh(np.concatenate([xa, xb]), np.concatenate([ua, ub]), lv, m, w, h)
+    ba = mo.render_mesh(np.concatenate([xb, xa]), np.concatenate([ub, ua]), lv, m, w, h)
+    assert (only_a != only_b).mean() > 0.5
+    # glDepthFunc(GL_LESS): a later fragment of equal depth does not replace the earlier one.  Depths of the two copies are
+    # interpolated from different corners, so they agree on most, not all, pixels: where they do, draw order decides.
+    assert (ab == only_a).mean() > 0.6 and (ba == only_b).mean() > 0.6 and (ab != ba).mean() > 0.3
+
+
+@pytest.mark.gpu
+def test_gpu_mesh_equal_depth_goes_to_the_triangle_drawn_first():
+    """The same on the device, bit for bit against the twin, whichever way the fragments travel: bins (large triangles),
+    the per-lane path (small ones), overflowing bins -- and run to run (the visibility key orders equal depths by triangle
+    index, so the order of the atomics does not show)."""
+    torch = pytest.importorskip("torch")
+    import orbslam2_nmi_amd as nmi
+    w, h = 160, 120
+    xa, ua, xb, ub, rgb, rp = _coplanar_scene(w, h)
+    mvps = np.stack([capi.render_mvp(rp, (0, 0, 0), (0, 0, 1), (0, -1, 0), t) for t in ((0, 0, 0), (0.3, -0.2, 0.5))])
+    lv = mo.mip_luma(rgb)
+    with nmi.NmiContext(w, h) as ctx, nmi.NmiTexture(ctx, rgb) as tex:
+        for first, second in (((xa, ua), (xb, ub)), ((xb, ub), (xa, ua))):
+            xyz, uv = np.concatenate([first[0], second[0]]), np.concatenate([first[1], second[1]])
+            exp = mo.render_stack(xyz, uv, lv, mvps, w, h)
+            dx, du = torch.from_numpy(xyz).cuda(), torch.from_numpy(uv).cuda()
+            outs = []
+            for cap in (255, 255, 3, 0):
+                ctx.set_option(ctx.OPT_TILE_QUEUE, cap)
+                outs.append(ctx.render_mesh(dx, du, tex, mvps).cpu().numpy())
+            assert all((outs[0] == o).all() for o in outs[1:])
+            diff = np.abs(outs[0].astype(int) - exp.astype(int))
+            assert ((outs[0] == 255) == (exp == 255)).all()
+            assert diff.max() <= 1 and (diff != 0).mean() < 2e-3, (diff.max(), (diff != 0).mean())
+
+
 @pytest.mark.gpu
 def test_gpu_mesh_to_winner_end_to_end():
     """mesh + texture + pose -> device render stack for a 3x3x1 translation grid; the frame is the mesh seen from a
