@@ -226,13 +226,15 @@ int nmi_sort_triangles(nmi_ctx *ctx, const float *d_xyz /*[3*T][3]*/, const floa
 
 /*
  * One whole search level on the device as a captured HIP graph: S renders of the cloud (nmi_render_points), Wn warps of the
- * frame (nmi_warp_stack) and the S x Wn search (nmi_search_grid) replay with a single hipGraphLaunch -- five kernel nodes
- * (parameter fetch + clear, splat, resolve, warp on a forked branch, search), no copy nodes.  Create once per (cloud, frame,
- * S, Wn); nmi_level_run takes this level's S view matrices (nmi_render_mvp, float[S][16]) and Wn forward homographies
- * (nmi_warp_homographies, double[Wn][9]) and blocks until the search has posted its winner to pinned host memory (the
- * context's stream drains a few microseconds later; work enqueued on it afterwards is ordered as usual).  Same results as
- * the three calls made one after the other.  The device pointers given at creation must stay valid and unchanged in
- * place (their contents may change between runs).
+ * frame (nmi_warp_stack) and the S x Wn search (nmi_search_grid) replay with a single hipGraphLaunch -- one chain of four
+ * kernel nodes (parameter fetch + clear; warp stack + splat in one launch; resolve; search), no copy nodes, no branches.
+ * Create once per (cloud, frame, S, Wn); nmi_level_run takes this level's S view matrices (nmi_render_mvp, float[S][16]) and
+ * Wn forward homographies (nmi_warp_homographies, double[Wn][9]) and blocks until the search has posted its winner to pinned
+ * host memory (the context's stream drains a few microseconds later; work enqueued on it afterwards is ordered as usual).
+ * Same results as the three calls made one after the other.  The MAP is taken as it is at creation: a point-cloud level
+ * keeps its own packed copy (16 bytes per point + one bounding box per 64 points), and d_xyz / d_red need not outlive the
+ * call; a mesh level reads d_xyz / d_uv and the texture in place (they must stay valid and unchanged).  d_frame must stay
+ * valid in place; its CONTENTS may change between runs (the next camera frame).
  */
 typedef struct nmi_level nmi_level;
 int nmi_level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int64_t n_points, const uint8_t *d_frame, int32_t S,

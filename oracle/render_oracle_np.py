@@ -46,9 +46,10 @@ def render_points(xyz, red, mvp_colmajor, width, height, point_size):
     cw = (m[3] * x + m[7] * y) + (m[11] * z + m[15])
     keep = (cw > 0) & (cx >= -cw) & (cx <= cw) & (cy >= -cw) & (cy <= cw) & (cz >= -cw) & (cz <= cw)
     cx, cy, cz, cw = cx[keep], cy[keep], cz[keep], cw[keep]
-    xw = (cx / cw * f32(0.5) + f32(0.5)) * f32(width)
-    yw = (cy / cw * f32(0.5) + f32(0.5)) * f32(height)
-    zw = cz / cw * f32(0.5) + f32(0.5)
+    iw = f32(1.0) / cw                                  # the perspective divide as one reciprocal and three products (splat_point)
+    xw = (cx * iw * f32(0.5) + f32(0.5)) * f32(width)
+    yw = (cy * iw * f32(0.5) + f32(0.5)) * f32(height)
+    zw = cz * iw * f32(0.5) + f32(0.5)
     depth = (zw * f32(16777215.0) + f32(0.5)).astype(np.uint32)
     colour = (np.clip(np.asarray(red, f32)[keep], 0, 1) * f32(255.0) + f32(0.5)).astype(np.uint32)
     frag = (depth << np.uint32(8)) | colour

@@ -23,6 +23,7 @@ struct nmi_level {
     int s_offset = 0, S_total = 0, w_offset = 0, Wn_total = 0;  // ... of an S_total x Wn_total level (block == level on one rank)
     uint8_t *d_renders = nullptr, *d_warps = nullptr;
     uint32_t *d_zbuf = nullptr;                 // point cloud: anchor buffer
+    void *d_packed = nullptr;                   // point cloud: the level's own packed copy of the cloud (16-byte records + wavefront boxes)
     nmi::MeshWork mesh;                         // textured mesh: the renderer's work area (kept clean by the renderer itself)
     bool is_mesh = false;
     float *d_mvps = nullptr, *h_mvps = nullptr, *d_coeffs = nullptr, *h_coeffs = nullptr;
@@ -45,7 +46,7 @@ int nmi_level_destroy(nmi_level *lv)
     (void)hipStreamSynchronize(lv->ctx->stream);
     if (lv->exec) (void)hipGraphExecDestroy(lv->exec);
     if (lv->graph) (void)hipGraphDestroy(lv->graph);
-    void *dev[] = {lv->d_renders, lv->d_warps, lv->d_zbuf, lv->d_mvps, lv->d_coeffs, lv->d_order, lv->d_key, lv->d_done, lv->d_ratings};
+    void *dev[] = {lv->d_packed, lv->d_renders, lv->d_warps, lv->d_zbuf, lv->d_mvps, lv->d_coeffs, lv->d_order, lv->d_key, lv->d_done, lv->d_ratings};
     for (void *q : dev)
         if (q) (void)hipFree(q);
     void *host[] = {lv->h_mvps, lv->h_coeffs, lv->h_key};
@@ -122,6 +123,8 @@ static int level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_attr, i
         if (mesh_work_alloc(ctx, S, &lv->mesh) != NMI_OK) e = hipErrorOutOfMemory;
     } else {
         ok(hipMalloc((void **)&lv->d_zbuf, nmi::render_zbuf_words(S, p.width, p.height, lv->size) * sizeof(uint32_t)));
+        ok(hipMalloc(&lv->d_packed, nmi::cloud_pack_bytes(n_points, nullptr) + 16));
+        if (e == hipSuccess) ok(nmi::launch_cloud_pack(d_xyz, d_red, n_points, lv->d_packed, ctx->stream));
     }
     ok(hipMalloc((void **)&lv->d_mvps, (size_t)S * 16 * sizeof(float)));
     ok(hipMalloc((void **)&lv->d_coeffs, (size_t)Wn * 9 * sizeof(float)));
@@ -185,18 +188,26 @@ static int level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_attr, i
         // (mesh: nothing to clear -- the renderer leaves its work area clean)
         ok(nmi::launch_level_prep(hd_mvps, lv->d_mvps, S * 16, hd_coeffs, lv->d_coeffs, Wn * 9, lv->d_key, lv->d_zbuf,
                                   tex ? 0 : nmi::render_zbuf_words(S, p.width, p.height, lv->size), st));
-        ok(hipEventRecord(lv->ev_fork, st));
-        ok(hipStreamWaitEvent(lv->side, lv->ev_fork, 0));
-        ok(nmi::launch_warp(d_frame, lv->d_coeffs, lv->d_warps, p.width, p.height, Wn, lv->side));
-        ok(hipEventRecord(lv->ev_join, lv->side));
+        // One chain of kernels when the warp blocks can ride along with the render's first kernel (the usual case: frame rows
+        // 16-byte aligned); otherwise the warp kernel runs on a forked branch beside the render.
+        const bool fused = nmi::level_front_eligible(d_frame, lv->d_warps, p.width, S) && n_points > 0;
+        if (!fused) {
+            ok(hipEventRecord(lv->ev_fork, st));
+            ok(hipStreamWaitEvent(lv->side, lv->ev_fork, 0));
+            ok(nmi::launch_warp(d_frame, lv->d_coeffs, lv->d_warps, p.width, p.height, Wn, lv->side));
+            ok(hipEventRecord(lv->ev_join, lv->side));
+        }
         if (tex)
             ok(nmi::launch_render_mesh(d_xyz, d_attr, n_points, tex->d_luma, tex->levels, tex->w, tex->h, tex->off, lv->d_mvps, S, lv->mesh, S,
                                        (int)(ctx->tile_queue_limit < 511 ? ctx->tile_queue_limit : 511), ctx->clip_queue_limit, lv->d_renders,
-                                       p.width, p.height, st));
+                                       p.width, p.height, st, fused ? d_frame : nullptr, lv->d_coeffs, lv->d_warps, Wn));
+        else if (fused)
+            ok(nmi::launch_level_front_points(lv->d_packed, n_points, lv->d_mvps, S, lv->d_zbuf, lv->d_renders, p.width, p.height, lv->size,
+                                              d_frame, lv->d_coeffs, lv->d_warps, Wn, st));
         else
             ok(nmi::launch_render_points(d_xyz, d_red, n_points, lv->d_mvps, S, lv->d_zbuf, lv->d_renders, p.width, p.height, lv->size, st,
                                          /*clear_first=*/false));
-        ok(hipStreamWaitEvent(st, lv->ev_join, 0));
+        if (!fused) ok(hipStreamWaitEvent(st, lv->ev_join, 0));
         ok(nmi::launch_grid(a, workgroups, true, st));
         hipError_t ec = hipStreamEndCapture(st, &lv->graph);
         ok(ec);

@@ -144,7 +144,10 @@ hipError_t launch_mesh_clear(const MeshWork &w, int S, int width, int height, hi
 hipError_t launch_render_mesh(const float *xyz, const float *uv, long long ntri, const float *luma, int levels, const int *lw,
                               const int *lh, const long long *loff, const float *mvps /*[S][16]*/, int S, const MeshWork &w,
                               int layout_views /* views the work area was allocated for (>= S) */, int bin_cap_limit,
-                              unsigned long long clip_cap_limit, uint8_t *out, int width, int height, hipStream_t stream);
+                              unsigned long long clip_cap_limit, uint8_t *out, int width, int height, hipStream_t stream,
+                              // a captured level: the Wn warps of `warp_frame` are made by extra workgroups of the first kernel
+                              // (level_front_eligible must hold; needs at least one triangle and S <= 64)
+                              const uint8_t *warp_frame = nullptr, const float *warp_coeffs = nullptr, uint8_t *warp_out = nullptr, int Wn = 0);
 // Words between rows of the renderers' anchor / depth buffer: the padded width, rounded so that the resolve pass can
 // read 8 consecutive anchors of any output quad with two aligned 16-byte loads (point sizes > 1); width for size 1.
 inline int zbuf_stride(int width, int size) { return size > 1 ? ((width + size - 1 + 3) & ~3) + 4 : width; }
@@ -156,6 +159,14 @@ hipError_t launch_render_points(const float *xyz, const float *red, long long np
 // Morton order of their positions.  Drains the stream.
 hipError_t sort_records_morton(const float *a, int na, int verts, const float *b, int nb, long long n, float *a_out, float *b_out,
                                hipStream_t stream);
+// Point-cloud level (nmi_level_create): the cloud packed once -- 16-byte point records + one bounding box per wavefront
+// (cloud_pack_bytes of device memory) -- and a front kernel that makes the warp stack and splats in one launch.
+size_t cloud_pack_bytes(long long npoints, size_t *boxes_offset);
+hipError_t launch_cloud_pack(const float *xyz, const float *red, long long npoints, void *packed, hipStream_t stream);
+bool level_front_eligible(const void *frame, const void *warps, int width, int S);
+hipError_t launch_level_front_points(const void *packed, long long npoints, const float *mvps, int S, uint32_t *zbuf, uint8_t *out,
+                                     int width, int height, int size, const uint8_t *frame, const float *coeffs, uint8_t *warps, int Wn,
+                                     hipStream_t stream);
 hipError_t launch_level_prep(const float *h_mvps, float *d_mvps, int n_mvps, const float *h_coeffs, float *d_coeffs, int n_coeffs,
                              unsigned long long *key, uint32_t *zbuf, size_t nz, hipStream_t stream);
 

@@ -37,6 +37,7 @@
 #include <stdlib.h>
 
 #include "nmi_kernels.h"
+#include "nmi_warp_device.h"
 
 namespace nmi {
 
@@ -456,21 +457,36 @@ __device__ __forceinline__ int bin_append(const BinGrid &g, int want, uint32_t i
 
 }  // namespace
 
+// (A captured level passes its warp stack's work along: the first wf.blocks workgroups of the launch are warp blocks,
+// nmi_warp_device.h, and the graph needs no branch for them.)
+struct WarpFuse {
+    const uint8_t *frame;
+    const float *coeffs;
+    uint8_t *warps;
+    int blocks;  // 0: none
+};
+
 __global__ __launch_bounds__(256) void nmi_mesh_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ uv, long long ntri,
                                                            const float *__restrict__ mvps, int views, int width, int height, BinGrid g,
                                                            ClipItem *__restrict__ clipq, unsigned long long *__restrict__ clip_state,
-                                                           unsigned long long clip_cap)
+                                                           unsigned long long clip_cap, int shares, WarpFuse wf)
 {
+    if ((int)blockIdx.x < wf.blocks) {
+        warp_lds_block_linear(wf.frame, wf.coeffs, wf.warps, width, height, (int)blockIdx.x, (int)threadIdx.x);
+        return;
+    }
+    const unsigned tri_blocks = (gridDim.x - (unsigned)wf.blocks) / (unsigned)shares;
+    const unsigned bid = blockIdx.x - (unsigned)wf.blocks, share = bid / tri_blocks, tri_block = bid - share * tri_blocks;
     __shared__ float m_all[kMaxViewsPerLaunch * 16];
     __shared__ float wave_box[4][6];
     __shared__ uint32_t beyond[kMaxViewsPerLaunch];
-    // blockIdx.y: which share of the views this block takes its 256 triangles through.  Few triangles -> many shares
+    // share: which part of the views this block takes its 256 triangles through.  Few triangles -> many shares
     // (4,800 triangles x 27 views: a lane per pair), so that the kernel is not 19 workgroups each walking 27 views through
     // dependent atomics; many triangles -> one share, the mesh is read once.
-    const int v_first = (int)(((long long)views * blockIdx.y) / gridDim.y), v_end = (int)(((long long)views * (blockIdx.y + 1)) / gridDim.y);
+    const int v_first = (int)(((long long)views * share) / shares), v_end = (int)(((long long)views * (share + 1)) / shares);
     for (int t = threadIdx.x + v_first * 16; t < v_end * 16; t += blockDim.x) m_all[t] = mvps[t];
     for (int t = threadIdx.x; t < views; t += blockDim.x) beyond[t] = (t >= v_first && t < v_end) ? 0x3Fu : 0u;
-    const long long tri = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const long long tri = tri_block * (long long)blockDim.x + threadIdx.x;
     const bool valid = tri < ntri;
     float px[3] = {0, 0, 0}, py[3] = {0, 0, 0}, pz[3] = {0, 0, 0}, tu[3], tv[3];
     if (valid) load_tri(xyz, uv, tri, px, py, pz, tu, tv);
@@ -899,9 +915,15 @@ hipError_t launch_mesh_clear(const MeshWork &w, int S, int width, int height, hi
 
 hipError_t launch_render_mesh(const float *xyz, const float *uv, long long ntri, const float *luma, int levels, const int *lw,
                               const int *lh, const long long *loff, const float *mvps, int S, const MeshWork &w, int layout_views,
-                              int bin_cap_limit, unsigned long long clip_cap_limit, uint8_t *out, int width, int height, hipStream_t stream)
+                              int bin_cap_limit, unsigned long long clip_cap_limit, uint8_t *out, int width, int height, hipStream_t stream,
+                              const uint8_t *warp_frame, const float *warp_coeffs, uint8_t *warp_out, int Wn)
 {
     if (S > layout_views) return hipErrorInvalidValue;
+    WarpFuse wf{warp_frame, warp_coeffs, warp_out, 0};
+    if (warp_frame) {
+        if (!warp_lds_eligible(warp_frame, warp_out, width) || ntri <= 0 || S > kMaxViewsPerLaunch) return hipErrorInvalidValue;
+        wf.blocks = warp_blocks_x(width) * warp_blocks_y(height) * Wn;
+    }
     if (ntri >= (1ll << 30) || width > 65535 || height > 65535) return hipErrorInvalidValue;  // triangle and piece share 31 bits of a key
     if (!w.zbuf || !w.bins || !w.state || !w.clip_queue || !w.clip_state) return hipErrorInvalidValue;
     MeshTexture tex{};
@@ -927,8 +949,8 @@ hipError_t launch_render_mesh(const float *xyz, const float *uv, long long ntri,
             // shares of the views: aim at ~half a million lanes
             long long shares = (500000 + ntri - 1) / ntri;
             shares = shares < 1 ? 1 : (shares > views ? views : shares);
-            hipLaunchKernelGGL(nmi_mesh_bin_kernel, dim3((unsigned)((ntri + 255) / 256), (unsigned)shares), dim3(256), 0, stream, xyz, uv, ntri,
-                               mvps + (size_t)s0 * 16, views, width, height, g, clipq, w.clip_state, clip_cap);
+            hipLaunchKernelGGL(nmi_mesh_bin_kernel, dim3((unsigned)(wf.blocks + ((ntri + 255) / 256) * shares)), dim3(256), 0, stream, xyz, uv, ntri,
+                               mvps + (size_t)s0 * 16, views, width, height, g, clipq, w.clip_state, clip_cap, (int)shares, wf);
             // (crossing triangles are few: an empty pass should cost little)
             hipLaunchKernelGGL(nmi_mesh_clip_kernel, dim3(64), dim3(256), 0, stream, xyz, uv, ntri, mvps + (size_t)s0 * 16, views, width,
                                height, g, clipq, w.clip_state, clip_cap);

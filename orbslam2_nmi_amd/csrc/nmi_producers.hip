@@ -3,8 +3,10 @@
 // renderer is in nmi_mesh.hip, the scoring kernels themselves in nmi_kernels.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "nmi_kernels.h"
+#include "nmi_warp_device.h"
 
 namespace nmi {
 
@@ -16,11 +18,6 @@ namespace nmi {
 // source coordinate coeff*(c0*x+c1*y+c2) in fp32; bilinear LinearFilter with floor(), the four taps accumulated in the
 // order (y1,x1) (y1,x2) (y2,x1) (y2,x2); saturate_cast<uchar> = round to nearest even) -- parity unpinned.
 // One thread produces 4 horizontally adjacent pixels of one warp and stores them as one dword.
-__device__ __forceinline__ float warp_tap(const uint8_t *__restrict__ src, int w, int h, int x, int y)
-{
-    return (x >= 0 && x < w && y >= 0 && y < h) ? (float)src[y * w + x] : 0.0f;  // BORDER_CONSTANT, value 0
-}
-
 __global__ __launch_bounds__(256) void nmi_warp_kernel(const uint8_t *__restrict__ frame, const float *__restrict__ coeffs,
                                                        uint8_t *__restrict__ out, int width, int height, int quads_per_row)
 {
@@ -81,164 +78,10 @@ __global__ __launch_bounds__(256) void nmi_warp_kernel(const uint8_t *__restrict
     }
 }
 
-// One output pixel with its taps taken from global memory (the arithmetic of nmi_warp_kernel, shared with the fallback of
-// the staged kernel below).
-__device__ __forceinline__ uint32_t warp_pixel_global(const uint8_t *__restrict__ frame, const float *__restrict__ c, int width, int height,
-                                                      int x, int y)
-{
-    const float fx = (float)x, fy = (float)y;
-    const float coeff = 1.0f / (c[6] * fx + c[7] * fy + c[8]);
-    const float xs = coeff * (c[0] * fx + c[1] * fy + c[2]);
-    const float ys = coeff * (c[3] * fx + c[4] * fy + c[5]);
-    float acc = 0.0f;
-    if (xs > -2.0f && xs < (float)(width + 1) && ys > -2.0f && ys < (float)(height + 1)) {
-        const int x1 = (int)floorf(xs), y1 = (int)floorf(ys);
-        const int x2 = x1 + 1, y2 = y1 + 1;
-        const float t11 = warp_tap(frame, width, height, x1, y1), t21 = warp_tap(frame, width, height, x2, y1);
-        const float t12 = warp_tap(frame, width, height, x1, y2), t22 = warp_tap(frame, width, height, x2, y2);
-        acc = acc + t11 * (((float)x2 - xs) * ((float)y2 - ys));
-        acc = acc + t21 * ((xs - (float)x1) * ((float)y2 - ys));
-        acc = acc + t12 * (((float)x2 - xs) * (ys - (float)y1));
-        acc = acc + t22 * ((xs - (float)x1) * (ys - (float)y1));
-    }
-    const float r = rintf(acc);
-    return r <= 0.0f ? 0u : (r >= 255.0f ? 255u : (uint32_t)r);
-}
-
-// The same warp with the source patch of each block staged in LDS.  nmi_warp_kernel spends its time on scattered tap
-// loads and the border tests around them (two 2-byte global loads per pixel with 64 different addresses per wave
-// instruction, four-way branching per tap near the border: 38 us for 27 warps at 848x480 = 0.58 TB/s of algorithmic
-// traffic).  A block's 128 x 32 output pixels take their taps from the image of that rectangle under the (inverse)
-// homography -- a convex quadrilateral, hence inside the bounding box of its four warped corners; for the grid's
-// rotations a patch of ~160 x 50 pixels.  The block fetches that patch once with coalesced 16-byte loads (frame rows
-// start on 16-byte boundaries: the width is a multiple of 16 here) INCLUDING a border of zeros wherever the box (grown by
-// the 2 pixels a tap can reach beyond the frame) sticks out of the frame, so that BORDER_CONSTANT(0) needs no test: every
-// tap of every pixel is one unconditional LDS byte read, and neighbouring lanes read neighbouring bytes of one dword,
-// which the LDS serves as a broadcast.  Arithmetic and its order are exactly nmi_warp_kernel's (the same fp32 twin
-// tests both).  Blocks whose patch exceeds the LDS budget, whose corners are not finite or whose homogeneous
-// coordinate is not positive at every corner take the global-tap form wholesale.
-constexpr int kWarpPatchBytes = 24 * 1024;
-constexpr int kWarpRowsPerThread = 4;  // a block covers 128 x 32 output pixels: one patch fetch per 4096 pixels
-
 __global__ __launch_bounds__(256) void nmi_warp_lds_kernel(const uint8_t *__restrict__ frame, const float *__restrict__ coeffs,
                                                            uint8_t *__restrict__ out, int width, int height, int quads_per_row)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t patch[kWarpPatchBytes + 16];  // + slack for the 8-byte tap windows
-    __shared__ int box[4];  // patch origin x (multiple of 16, may be -16), origin y (may be negative), pitch in bytes (0 = no patch), rows
-    constexpr int kBlockRows = 8 * kWarpRowsPerThread;
-    const int tid = threadIdx.y * 32 + threadIdx.x;
-    const int q = blockIdx.x * 32 + threadIdx.x;
-    const int wi = blockIdx.z;
-    const float *c = coeffs + wi * 9;
-    if (tid < 64) {
-        // lanes 0..3: the four corners of this block's pixel rectangle, through the same fp32 expressions as the pixels
-        const int bx0 = blockIdx.x * 128, by0 = blockIdx.y * kBlockRows;
-        const int bx1 = min(bx0 + 127, width - 1), by1 = min(by0 + kBlockRows - 1, height - 1);
-        const float fx = (float)((tid & 1) ? bx1 : bx0), fy = (float)((tid & 2) ? by1 : by0);
-        const float den = c[6] * fx + c[7] * fy + c[8];
-        const float coeff = 1.0f / den;
-        const float xs = coeff * (c[0] * fx + c[1] * fy + c[2]);
-        const float ys = coeff * (c[3] * fx + c[4] * fy + c[5]);
-        const bool good = den > 0.0f && fabsf(xs) < 1e8f && fabsf(ys) < 1e8f;  // also false for NaN
-        float xlo = xs, xhi = xs, ylo = ys, yhi = ys;
-        bool all_good = good;
-#pragma unroll
-        for (int off = 1; off < 4; off <<= 1) {
-            xlo = fminf(xlo, __shfl_xor(xlo, off, 64));
-            xhi = fmaxf(xhi, __shfl_xor(xhi, off, 64));
-            ylo = fminf(ylo, __shfl_xor(ylo, off, 64));
-            yhi = fmaxf(yhi, __shfl_xor(yhi, off, 64));
-            all_good = all_good && __shfl_xor((int)all_good, off, 64) != 0;
-        }
-        if (tid == 0) {
-            int pitch = 0, rows = 0, px0 = 0, py0 = 0;
-            if (all_good) {
-                // taps of pixels that pass the range test lie in [-2, width + 1] x [-2, height + 1]; 2 pixels of margin
-                // around the corners' box absorb floor / +1 and the rounding of the transform
-                const int x_lo = max((int)floorf(xlo) - 2, -2), x_hi = min((int)floorf(xhi) + 3, width + 1);
-                const int y_lo = max((int)floorf(ylo) - 2, -2), y_hi = min((int)floorf(yhi) + 3, height + 1);
-                if (x_lo <= x_hi && y_lo <= y_hi) {
-                    px0 = x_lo < 0 ? -16 : (x_lo & ~15);
-                    py0 = y_lo;
-                    pitch = ((x_hi - px0 + 1) + 15) & ~15;
-                    rows = y_hi - y_lo + 1;
-                    if (pitch * rows > kWarpPatchBytes) pitch = 0, rows = 0;  // too large: global taps
-                } else {
-                    px0 = -16, py0 = -2, pitch = 16, rows = 2;  // nothing in reach: two border rows of zeros serve every (clamped) tap
-                }
-            }
-            box[0] = px0, box[1] = py0, box[2] = pitch, box[3] = rows;
-        }
-    }
-    __syncthreads();
-    const int px0 = box[0], py0 = box[1], pitch = box[2], rows = box[3];
-    if (pitch == 0) {  // block-uniform fallback
-        if (q >= quads_per_row) return;
-        for (int rr = 0; rr < kWarpRowsPerThread; ++rr) {
-            const int y = blockIdx.y * kBlockRows + rr * 8 + threadIdx.y;
-            if (y >= height) break;
-            uint32_t packed = 0;
-            for (int k = 0; k < 4; ++k) packed |= warp_pixel_global(frame, c, width, height, q * 4 + k, y) << (8 * k);
-            *reinterpret_cast<uint32_t *>(out + ((size_t)wi * height + y) * width + q * 4) = packed;
-        }
-        return;
-    }
-    {
-        const int units_per_row = pitch >> 4, units = units_per_row * rows;
-        const uint4 zero = {0, 0, 0, 0};
-        for (int u = tid; u < units; u += 256) {
-            const int r = u / units_per_row, cx = u - r * units_per_row;
-            const int fy = py0 + r, fx = px0 + cx * 16;  // a 16-byte unit is wholly inside or wholly outside the frame
-            uint4 v = zero;
-            if (fy >= 0 && fy < height && fx >= 0 && fx < width) v = *reinterpret_cast<const uint4 *>(frame + (size_t)fy * width + fx);
-            *reinterpret_cast<uint4 *>(patch + r * pitch + cx * 16) = v;
-        }
-    }
-    __syncthreads();
-    if (q >= quads_per_row) return;
-    const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5], c6 = c[6], c7 = c[7], c8 = c[8];
-    const float xmax = (float)(width + 1), ymax = (float)(height + 1);
-#pragma unroll 1
-    for (int rr = 0; rr < kWarpRowsPerThread; ++rr) {
-        const int y = blockIdx.y * kBlockRows + rr * 8 + threadIdx.y;
-        if (y >= height) break;
-        const float fy = (float)y;
-        uint32_t packed = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float fx = (float)(q * 4 + k);
-            const float coeff = 1.0f / (c6 * fx + c7 * fy + c8);
-            const float xs = coeff * (c0 * fx + c1 * fy + c2);
-            const float ys = coeff * (c3 * fx + c4 * fy + c5);
-            // nmi_warp_kernel gives 0 to pixels whose source lies outside (-2, width + 1) x (-2, height + 1).  Clamping the
-            // source coordinate into that closed range does the same without a test: a clamped coordinate has both of its
-            // taps (or its whole 2 x 2 window) in the zero border, and it stays inside this block's patch because the patch
-            // is the corners' bounding box clipped to the very same range.
-            const float xsc = __builtin_amdgcn_fmed3f(xs, -2.0f, xmax), ysc = __builtin_amdgcn_fmed3f(ys, -2.0f, ymax);
-            const float x1f = floorf(xsc), y1f = floorf(ysc);
-            // (unsigned min: a negative offset -- impossible while the bounding-box argument holds -- also ends up inside)
-            const uint32_t lx = min((uint32_t)((int)x1f - px0), (uint32_t)(pitch - 2)), ly = min((uint32_t)((int)y1f - py0), (uint32_t)(rows - 2));
-            // The two taps of a row are bytes o, o + 1 of the patch with o of any alignment.  An unaligned 2-byte LDS read
-            // costs ~200 cycles of issue stall (measured: SQ_WAIT_INST_LDS 55 units per ds_read_u16, the whole kernel 40 us
-            // however its taps were fetched), so the 8 aligned bytes around them are read and shifted instead.
-            const uint32_t o = ly * (uint32_t)pitch + lx;
-            const uint32_t *w0 = reinterpret_cast<const uint32_t *>(patch + (o & ~3u));
-            const uint32_t *w1 = reinterpret_cast<const uint32_t *>(patch + (o & ~3u) + pitch);
-            const uint32_t top = __builtin_amdgcn_alignbyte(w0[1], w0[0], o & 3u);
-            const uint32_t bot = __builtin_amdgcn_alignbyte(w1[1], w1[0], o & 3u);
-            const float t11 = (float)(top & 0xFFu), t21 = (float)((top >> 8) & 0xFFu);
-            const float t12 = (float)(bot & 0xFFu), t22 = (float)((bot >> 8) & 0xFFu);
-            const float x2f = x1f + 1.0f, y2f = y1f + 1.0f;  // exact: small integers
-            float acc = 0.0f;
-            acc = acc + t11 * ((x2f - xsc) * (y2f - ysc));
-            acc = acc + t21 * ((xsc - x1f) * (y2f - ysc));
-            acc = acc + t12 * ((x2f - xsc) * (ysc - y1f));
-            acc = acc + t22 * ((xsc - x1f) * (ysc - y1f));
-            // saturate_cast<uchar>: round to nearest even, clamp; acc >= 0, and the pack instruction saturates at 255
-            packed = __builtin_amdgcn_cvt_pk_u8_f32(rintf(acc), k, packed);
-        }
-        *reinterpret_cast<uint32_t *>(out + ((size_t)wi * height + y) * width + q * 4) = packed;
-    }
+    warp_lds_block(frame, coeffs, out, width, height, quads_per_row, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)threadIdx.x, (int)threadIdx.y);
 }
 
 hipError_t launch_warp(const uint8_t *frame, const float *coeffs, uint8_t *out, int width, int height, int Wn,
@@ -294,7 +137,7 @@ __global__ __launch_bounds__(256) void nmi_level_prep_kernel(const float *__rest
 hipError_t launch_level_prep(const float *h_mvps, float *d_mvps, int n_mvps, const float *h_coeffs, float *d_coeffs, int n_coeffs,
                              unsigned long long *key, uint32_t *zbuf, size_t nz, hipStream_t stream)
 {
-    hipLaunchKernelGGL(nmi_level_prep_kernel, dim3(2048), dim3(256), 0, stream, h_mvps, d_mvps, n_mvps, h_coeffs, d_coeffs, n_coeffs, key,
+    hipLaunchKernelGGL(nmi_level_prep_kernel, dim3(nz ? 2048 : 1), dim3(256), 0, stream, h_mvps, d_mvps, n_mvps, h_coeffs, d_coeffs, n_coeffs, key,
                        zbuf, nz);
     return hipGetLastError();
 }
@@ -339,9 +182,11 @@ __device__ __forceinline__ void splat_point(const float *__restrict__ m, float x
     const float cz = (m[2] * x + m[6] * y) + (m[10] * z + m[14]);
     const float cw = (m[3] * x + m[7] * y) + (m[11] * z + m[15]);
     if (!(cw > 0.0f) || cx < -cw || cx > cw || cy < -cw || cy > cw || cz < -cw || cz > cw) return;  // point clipping
-    const float xw = (cx / cw * 0.5f + 0.5f) * (float)width;
-    const float yw = (cy / cw * 0.5f + 0.5f) * (float)height;
-    const float zw = cz / cw * 0.5f + 0.5f;
+    // the perspective divide as one (correctly rounded) reciprocal and three products: a third of the three divisions' cost
+    const float iw = 1.0f / cw;
+    const float xw = (cx * iw * 0.5f + 0.5f) * (float)width;
+    const float yw = (cy * iw * 0.5f + 0.5f) * (float)height;
+    const float zw = cz * iw * 0.5f + 0.5f;
     const uint32_t depth = (uint32_t)(zw * 16777215.0f + 0.5f);
     const uint32_t frag = (depth << 8) | colour;
     int x0, y0;
@@ -362,38 +207,63 @@ __device__ __forceinline__ void splat_point(const float *__restrict__ m, float x
     atomicMin(&zbuf[((size_t)s * hp + ay) * stride + ax], frag);
 }
 
-// P = points per lane.  Two (a wavefront takes 128 consecutive points: half the culling per point, two loads in flight)
-// measured slower than one: 107 vs 93 us for clear + splat + resolve of 3 M points x 27 views.
-template <int P>
-__global__ __launch_bounds__(256) void nmi_splat_kernel(const float *__restrict__ xyz, const float *__restrict__ red, long long npoints,
-                                                        const float *__restrict__ mvps, int views, uint32_t *__restrict__ zbuf,
-                                                        int width, int height, int size, int stride)
+// The cloud as a level keeps it (nmi_level_create): one 16-byte record per point -- x, y, z, red -- so that a lane fetches its
+// point with ONE load instead of four 4-byte loads 12 bytes apart, and the bounding box of every wavefront's 64 points,
+// computed once (the cloud of a level does not change), instead of 36 cross-lane reductions per wavefront and launch.
+struct PackedCloud {
+    const float4 *points;  // [n]
+    const float4 *boxes;   // [2 * ceil(n / 64)]: lo.xyz, hi.xyz of each wavefront's points
+};
+
+__global__ __launch_bounds__(256) void nmi_cloud_pack_kernel(const float *__restrict__ xyz, const float *__restrict__ red, long long npoints,
+                                                             float4 *__restrict__ points, float4 *__restrict__ boxes)
 {
-    const int lane = (int)(threadIdx.x & 63);
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const bool valid = i < npoints;
+    const float inf = __builtin_huge_valf();
+    float x = 0.0f, y = 0.0f, z = 0.0f, r = 0.0f;
+    if (valid) {
+        x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2], r = red[i];
+        points[i] = make_float4(x, y, z, r);
+    }
+    const float lox = wave_min(valid ? x : inf), loy = wave_min(valid ? y : inf), loz = wave_min(valid ? z : inf);
+    const float hix = wave_max(valid ? x : -inf), hiy = wave_max(valid ? y : -inf), hiz = wave_max(valid ? z : -inf);
+    if ((threadIdx.x & 63) == 0 && valid) {
+        boxes[2 * (i >> 6)] = make_float4(lox, loy, loz, 0.0f);
+        boxes[2 * (i >> 6) + 1] = make_float4(hix, hiy, hiz, 0.0f);
+    }
+}
+
+// The 64 points of wavefront `wave` of the launch (lane = this lane) into the views' anchor buffers.
+// (One point per lane: two -- a wavefront taking 128 consecutive points, half the culling per point, two loads in flight --
+// measured slower, 107 vs 93 us for clear + splat + resolve of 3 M points x 27 views.)
+template <bool PACKED>
+__device__ __forceinline__ void splat_wave(const float *__restrict__ xyz, const float *__restrict__ red, PackedCloud pc, long long npoints,
+                                           const float *__restrict__ mvps, int views, uint32_t *__restrict__ zbuf, int width, int height,
+                                           int size, int stride, long long wave, int lane)
+{
     // lane v's view matrix for the culling test below: asked for first, it is needed last
     const float4 *mv = reinterpret_cast<const float4 *>(mvps + (size_t)(lane < views ? lane : 0) * 16);  // column-major like glm: m[c*4 + r]
     const float4 c0 = mv[0], c1 = mv[1], c2 = mv[2], c3 = mv[3];
-    const long long wave = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
-    bool valid[P];
-    float x[P], y[P], z[P], r[P];
-#pragma unroll
-    for (int q = 0; q < P; ++q) {
-        const long long i = (wave * P + q) * 64 + lane;
-        valid[q] = i < npoints;
-        x[q] = y[q] = z[q] = r[q] = 0.0f;
-        if (valid[q]) x[q] = xyz[3 * i], y[q] = xyz[3 * i + 1], z[q] = xyz[3 * i + 2], r[q] = red[i];
+    const long long i = wave * 64 + lane;
+    const bool valid = i < npoints;
+    float x = 0.0f, y = 0.0f, z = 0.0f, r = 0.0f;
+    float lox, loy, loz, hix, hiy, hiz;
+    if (PACKED) {
+        if (valid) {
+            const float4 p = pc.points[i];
+            x = p.x, y = p.y, z = p.z, r = p.w;
+        }
+        const float4 lo = pc.boxes[2 * wave], hi = pc.boxes[2 * wave + 1];  // the same address for the whole wavefront
+        lox = lo.x, loy = lo.y, loz = lo.z, hix = hi.x, hiy = hi.y, hiz = hi.z;
+    } else {
+        if (valid) x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2], r = red[i];
+        const float inf = __builtin_huge_valf();
+        lox = wave_min(valid ? x : inf), loy = wave_min(valid ? y : inf), loz = wave_min(valid ? z : inf);
+        hix = wave_max(valid ? x : -inf), hiy = wave_max(valid ? y : -inf), hiz = wave_max(valid ? z : -inf);
     }
 
     // ---- which views can these points reach? ----
-    const float inf = __builtin_huge_valf();
-    float lx = inf, ly = inf, lz = inf, hx = -inf, hy = -inf, hz = -inf;
-#pragma unroll
-    for (int q = 0; q < P; ++q) {
-        lx = fminf(lx, valid[q] ? x[q] : inf), ly = fminf(ly, valid[q] ? y[q] : inf), lz = fminf(lz, valid[q] ? z[q] : inf);
-        hx = fmaxf(hx, valid[q] ? x[q] : -inf), hy = fmaxf(hy, valid[q] ? y[q] : -inf), hz = fmaxf(hz, valid[q] ? z[q] : -inf);
-    }
-    const float lox = wave_min(lx), loy = wave_min(ly), loz = wave_min(lz);
-    const float hix = wave_max(hx), hiy = wave_max(hy), hiz = wave_max(hz);
     const float ax = fmaxf(fabsf(lox), fabsf(hix)), ay = fmaxf(fabsf(loy), fabsf(hiy)), az = fmaxf(fabsf(loz), fabsf(hiz));
     bool outside = lane >= views;
     {
@@ -419,18 +289,39 @@ __global__ __launch_bounds__(256) void nmi_splat_kernel(const float *__restrict_
     }
     unsigned long long todo = ~__ballot(outside);
     if (views < 64) todo &= (1ull << views) - 1ull;
-
-    uint32_t colour[P];
-#pragma unroll
-    for (int q = 0; q < P; ++q) colour[q] = (uint32_t)(fminf(fmaxf(r[q], 0.0f), 1.0f) * 255.0f + 0.5f);
+    const uint32_t colour = (uint32_t)(fminf(fmaxf(r, 0.0f), 1.0f) * 255.0f + 0.5f);
     while (todo) {  // wavefront-uniform
         const int s = __builtin_ctzll(todo);
         todo &= todo - 1ull;
-        const float *m = mvps + (size_t)s * 16;  // uniform address: scalar loads
-#pragma unroll
-        for (int q = 0; q < P; ++q)
-            if (valid[q]) splat_point(m, x[q], y[q], z[q], colour[q], zbuf, s, width, height, size, stride);
+        // uniform address: scalar loads.  (Taking the matrix from the registers of lane s, where the culling test already has it,
+        // with 16 lane reads instead: 72 vs 64 us for the level's front kernel -- the scalar cache serves these loads.)
+        const float *m = mvps + (size_t)s * 16;
+        if (valid) splat_point(m, x, y, z, colour, zbuf, s, width, height, size, stride);
     }
+}
+
+__global__ __launch_bounds__(256) void nmi_splat_kernel(const float *__restrict__ xyz, const float *__restrict__ red, long long npoints,
+                                                        const float *__restrict__ mvps, int views, uint32_t *__restrict__ zbuf,
+                                                        int width, int height, int size, int stride)
+{
+    splat_wave<false>(xyz, red, PackedCloud{}, npoints, mvps, views, zbuf, width, height, size, stride,
+                      (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6, (int)(threadIdx.x & 63));
+}
+
+// The front kernel of a captured point-cloud level: its first `warp_blocks` workgroups make the warp stack
+// (nmi_warp_device.h), the others splat the packed cloud -- one kernel node instead of a fork and a join in the graph.
+__global__ __launch_bounds__(256) void nmi_level_front_kernel(PackedCloud pc, long long npoints, const float *__restrict__ mvps, int views,
+                                                              uint32_t *__restrict__ zbuf, int width, int height, int size, int stride,
+                                                              const uint8_t *__restrict__ frame, const float *__restrict__ coeffs,
+                                                              uint8_t *__restrict__ warps, int warp_blocks)
+{
+    if ((int)blockIdx.x < warp_blocks) {
+        warp_lds_block_linear(frame, coeffs, warps, width, height, (int)blockIdx.x, (int)threadIdx.x);
+        return;
+    }
+    const long long b = (long long)blockIdx.x - warp_blocks;
+    splat_wave<true>(nullptr, nullptr, pc, npoints, mvps, views, zbuf, width, height, size, stride, (b * 256 + threadIdx.x) >> 6,
+                     (int)(threadIdx.x & 63));
 }
 
 // Resolve.  Four horizontally adjacent output pixels per lane: the size x (size+3) anchor window is read once and the
@@ -530,7 +421,7 @@ hipError_t launch_render_points(const float *xyz, const float *red, long long np
         const size_t per_view = (size_t)stride * (height + size - 1);
         for (int s0 = 0; s0 < S; s0 += kMaxViewsPerLaunch) {
             const int views = S - s0 < kMaxViewsPerLaunch ? S - s0 : kMaxViewsPerLaunch;
-            hipLaunchKernelGGL(nmi_splat_kernel<1>, dim3((unsigned)((npoints + 255) / 256)), dim3(256), 0, stream, xyz, red, npoints,
+            hipLaunchKernelGGL(nmi_splat_kernel, dim3((unsigned)((npoints + 255) / 256)), dim3(256), 0, stream, xyz, red, npoints,
                                mvps + (size_t)s0 * 16, views, zbuf + (size_t)s0 * per_view, width, height, size, stride);
         }
     }
@@ -538,5 +429,46 @@ hipError_t launch_render_points(const float *xyz, const float *red, long long np
     (void)n;
     return hipGetLastError();
 }
+
+size_t cloud_pack_bytes(long long npoints, size_t *boxes_offset)
+{
+    const size_t pts = ((size_t)npoints * sizeof(float4) + 255) & ~(size_t)255;
+    if (boxes_offset) *boxes_offset = pts;
+    return pts + (size_t)((npoints + 63) / 64) * 2 * sizeof(float4);
+}
+
+hipError_t launch_cloud_pack(const float *xyz, const float *red, long long npoints, void *packed, hipStream_t stream)
+{
+    size_t off = 0;
+    (void)cloud_pack_bytes(npoints, &off);
+    if (npoints > 0)
+        hipLaunchKernelGGL(nmi_cloud_pack_kernel, dim3((unsigned)((npoints + 255) / 256)), dim3(256), 0, stream, xyz, red, npoints,
+                           reinterpret_cast<float4 *>(packed), reinterpret_cast<float4 *>(static_cast<char *>(packed) + off));
+    return hipGetLastError();
+}
+
+// Front of a captured point-cloud level: warp stack + splat in one launch (no clear: the level's prep node did it), then
+// the resolve.  S <= 64 views.
+hipError_t launch_level_front_points(const void *packed, long long npoints, const float *mvps, int S, uint32_t *zbuf, uint8_t *out,
+                                     int width, int height, int size, const uint8_t *frame, const float *coeffs, uint8_t *warps, int Wn,
+                                     hipStream_t stream)
+{
+    if (S > kMaxViewsPerLaunch || !warp_lds_eligible(frame, warps, width)) return hipErrorInvalidValue;
+    size_t off = 0;
+    (void)cloud_pack_bytes(npoints, &off);
+    PackedCloud pc{reinterpret_cast<const float4 *>(packed), reinterpret_cast<const float4 *>(static_cast<const char *>(packed) + off)};
+    int warp_blocks = warp_blocks_x(width) * warp_blocks_y(height) * Wn;
+    long long splat_blocks = (npoints + 255) / 256;
+    static const int dbg = getenv("NMI_FRONT_DBG") ? atoi(getenv("NMI_FRONT_DBG")) : 0;  // profiling ablations (tools only): 1 no warp blocks, 2 no splat blocks
+    if (dbg & 1) warp_blocks = 0;
+    if (dbg & 2) splat_blocks = 0, npoints = 0;
+    const int stride = zbuf_stride(width, size);
+    hipLaunchKernelGGL(nmi_level_front_kernel, dim3((unsigned)(warp_blocks + splat_blocks)), dim3(256), 0, stream, pc, npoints, mvps, S, zbuf,
+                       width, height, size, stride, frame, coeffs, warps, warp_blocks);
+    launch_resolve(zbuf, out, S, width, height, size, stream);
+    return hipGetLastError();
+}
+
+bool level_front_eligible(const void *frame, const void *warps, int width, int S) { return S <= kMaxViewsPerLaunch && warp_lds_eligible(frame, warps, width); }
 
 }  // namespace nmi

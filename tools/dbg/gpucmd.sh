@@ -1,3 +1,3 @@
-mkdir -p $GRAFT_REPO_ROOT/gpurun_out/r03_o
-timeout -k 10 300 python3 -m pytest tests/test_render.py tests/test_level_sharded.py tests/test_config5.py -q -m gpu > gpurun_out/r03_o/mesh_tests.log 2>&1; echo rc=$? >> gpurun_out/r03_o/mesh_tests.log; tail -4 gpurun_out/r03_o/mesh_tests.log
-timeout -k 10 200 python3 tools/mesh_time.py > gpurun_out/r03_o/mesh_time.txt 2>&1; cat gpurun_out/r03_o/mesh_time.txt
+mkdir -p $GRAFT_REPO_ROOT/gpurun_out/r03_r
+cd /tmp && export TMPDIR=/tmp
+for dbg in 0 1 2; do NMI_FRONT_DBG=$dbg rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r03_r/trace_$dbg -- python3 $GRAFT_REPO_ROOT/bench.py --config e2e --keyframes 20 > $GRAFT_REPO_ROOT/gpurun_out/r03_r/trace_$dbg.log 2>&1; grep -h "front_kernel\|resolve" $GRAFT_REPO_ROOT/gpurun_out/r03_r/trace_$dbg/*/*kernel_stats.csv | cut -d, -f1-4 | cut -c1-40,100-200; done
