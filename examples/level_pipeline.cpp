@@ -1,6 +1,7 @@
 // level_pipeline.cpp -- C++ host program: keyframe refinement with EVERYTHING on the device.
 //
-// The map is a coloured point cloud in HBM (nmi_prop_RENDER 4), the camera frame is in HBM; per iteration of
+// The map is a coloured point cloud (nmi_prop_RENDER 4) or, with --mesh, a textured triangle mesh (nmi_prop_RENDER 1, the
+// reference's default, allProperties.hpp:41) in HBM, the camera frame is in HBM; per iteration of
 // Tracking::RelocalizeWithNMIStrategy (Tracking.cc:1987-2179, here nmi_relocalize_with_strategy) the host computes 27 view
 // matrices (Rendering::calculateTranslationCV + the MVP of rendering.hpp:196-202) and 27 homographies (image.cpp:76-107)
 // and replays ONE captured HIP graph (nmi_level_run): renders, warps, the 729-candidate search, winner back.  Only
@@ -80,9 +81,29 @@ int eval_level(void *user, const nmi_search_kernel *g, const float Twc[16], int6
 
 }  // namespace
 
+// The map's relief and texture (shared by the point cloud and the mesh form).
+static float surface_z(float u, float v) { return DEPTH + 3.0f * sinf(0.012f * u) * cosf(0.015f * v); }
+static float surface_grey(float u, float v, float n)
+{
+    const float t = 128.0f + 45.0f * sinf(0.031f * u + 0.6f * sinf(0.017f * v)) + 40.0f * cosf(0.043f * v + 0.011f * u) +
+                    18.0f * sinf(0.11f * (u + v)) + 10.0f * n;
+    return fminf(fmaxf(t, 0.0f), 255.0f);
+}
+
 int main(int argc, char **argv)
 {
-    const int keyframes = argc > 1 ? atoi(argv[1]) : 200;
+    // usage: level_pipeline [keyframes] [--mesh [NXxNY]]   (--mesh: nmi_prop_RENDER 1, the reference's default render mode:
+    // the same surface as NX x NY quads = 2 NX NY textured triangles, default 300x200 = 120,000)
+    int keyframes = 200, mesh_nx = 0, mesh_ny = 0;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--mesh")) {
+            mesh_nx = 300, mesh_ny = 200;
+            if (i + 1 < argc && sscanf(argv[i + 1], "%dx%d", &mesh_nx, &mesh_ny) == 2) ++i;
+        } else {
+            keyframes = atoi(argv[i]);
+        }
+    }
+    const bool mesh = mesh_nx > 0 && mesh_ny > 0;
     nmi_params prm;
     CHECK_NMI(nmi_params_default(&prm, W, H));
     nmi_ctx *ctx = nullptr;
@@ -90,25 +111,52 @@ int main(int argc, char **argv)
 
     // The map: a textured, undulating surface about 10 m ahead, three frame-widths wide, ~0.8 points per pixel of a view
     // (3 M points).
-    const int nu = (int)(3 * W * 0.9), nv = (int)(3 * H * 0.9);
-    std::vector<float> xyz((size_t)nu * nv * 3), red((size_t)nu * nv);
+    // (relief of +-3 m: on a flat wall a sideways step and a small turn of the camera move the image alike, and the 6-D search
+    // could not tell them apart)
+    std::vector<float> xyz, red;  // point cloud: positions [N][3] + red [N]; mesh: corners [3T][3] + uv [3T][2]
+    nmi_texture *tex = nullptr;
     unsigned s = 2468u;
-    for (int j = 0; j < nv; ++j)
-        for (int i = 0; i < nu; ++i) {
-            const float u = -W + 3.0f * W * i / (nu - 1), v = -H + 3.0f * H * j / (nv - 1);
-            const size_t k = (size_t)j * nu + i;
-            // relief of +-3 m: on a flat wall a sideways step and a small turn of the camera move the image alike, and
-            // the 6-D search could not tell them apart
-            const float z = DEPTH + 3.0f * sinf(0.012f * u) * cosf(0.015f * v);
-            xyz[3 * k] = (u - (float)CX) / (float)FX * z;
-            xyz[3 * k + 1] = (v - (float)CY) / (float)FY * z;
-            xyz[3 * k + 2] = z;
-            s = s * 1664525u + 1013904223u;
-            const float n = ((s >> 8) & 0xFFFF) / 65535.0f - 0.5f;
-            const float t = 128.0f + 45.0f * sinf(0.031f * u + 0.6f * sinf(0.017f * v)) + 40.0f * cosf(0.043f * v + 0.011f * u) +
-                            18.0f * sinf(0.11f * (u + v)) + 10.0f * n;
-            red[k] = fminf(fmaxf(t, 0.0f), 255.0f) / 256.0f;  // objloader.cpp:261: colour / 256
-        }
+    if (!mesh) {
+        const int nu = (int)(3 * W * 0.9), nv = (int)(3 * H * 0.9);
+        xyz.resize((size_t)nu * nv * 3), red.resize((size_t)nu * nv);
+        for (int j = 0; j < nv; ++j)
+            for (int i = 0; i < nu; ++i) {
+                const float u = -W + 3.0f * W * i / (nu - 1), v = -H + 3.0f * H * j / (nv - 1);
+                const size_t k = (size_t)j * nu + i;
+                const float z = surface_z(u, v);
+                xyz[3 * k] = (u - (float)CX) / (float)FX * z;
+                xyz[3 * k + 1] = (v - (float)CY) / (float)FY * z;
+                xyz[3 * k + 2] = z;
+                s = s * 1664525u + 1013904223u;
+                red[k] = surface_grey(u, v, ((s >> 8) & 0xFFFF) / 65535.0f - 0.5f) / 256.0f;  // objloader.cpp:261: colour / 256
+            }
+    } else {
+        // texture: the surface's grey values on a 2048 x 1024 raster (what loadBMP_custom would hand to glTexImage2D, texture.cpp:31-86)
+        const int tw = 2048, th = 1024;
+        std::vector<uint8_t> rgb((size_t)tw * th * 3);
+        for (int j = 0; j < th; ++j)
+            for (int i = 0; i < tw; ++i) {
+                const float u = -W + 3.0f * W * (i + 0.5f) / tw, v = -H + 3.0f * H * (j + 0.5f) / th;
+                s = s * 1664525u + 1013904223u;
+                const uint8_t g = (uint8_t)lrintf(surface_grey(u, v, ((s >> 8) & 0xFFFF) / 65535.0f - 0.5f));
+                rgb[((size_t)j * tw + i) * 3] = rgb[((size_t)j * tw + i) * 3 + 1] = rgb[((size_t)j * tw + i) * 3 + 2] = g;
+            }
+        CHECK_NMI(nmi_texture_create(ctx, rgb.data(), tw, th, &tex));
+        xyz.resize((size_t)mesh_nx * mesh_ny * 6 * 3), red.resize((size_t)mesh_nx * mesh_ny * 6 * 2);
+        size_t k = 0;
+        auto corner = [&](int i, int j) {
+            const float u = -W + 3.0f * W * i / mesh_nx, v = -H + 3.0f * H * j / mesh_ny, z = surface_z(u, v);
+            xyz[3 * k] = (u - (float)CX) / (float)FX * z, xyz[3 * k + 1] = (v - (float)CY) / (float)FY * z, xyz[3 * k + 2] = z;
+            red[2 * k] = (float)i / mesh_nx, red[2 * k + 1] = (float)j / mesh_ny;
+            ++k;
+        };
+        for (int j = 0; j < mesh_ny; ++j)
+            for (int i = 0; i < mesh_nx; ++i) {  // two triangles per quad, counter-clockwise as this camera (y down) sees them
+                corner(i, j), corner(i + 1, j + 1), corner(i + 1, j);
+                corner(i, j), corner(i, j + 1), corner(i + 1, j + 1);
+            }
+    }
+    const int64_t n_prims = mesh ? (int64_t)mesh_nx * mesh_ny * 2 : (int64_t)red.size();
     float *d_xyz = nullptr, *d_red = nullptr;
     uint8_t *d_frame = nullptr, *d_tmp = nullptr;
     CHECK_HIP(hipMalloc((void **)&d_xyz, xyz.size() * sizeof(float)));
@@ -132,7 +180,10 @@ int main(int argc, char **argv)
         const float zero[3] = {0, 0, 0};
         float mvp[16];
         CHECK_NMI(nmi_render_mvp(&p.rp, pos, look, up, zero, mvp));
-        CHECK_NMI(nmi_render_points(ctx, d_xyz, d_red, (int64_t)red.size(), mvp, 1, p.rp.point_size, d_tmp));
+        if (mesh)
+            CHECK_NMI(nmi_render_mesh(ctx, d_xyz, d_red, n_prims, tex, mvp, 1, d_tmp));
+        else
+            CHECK_NMI(nmi_render_points(ctx, d_xyz, d_red, n_prims, mvp, 1, p.rp.point_size, d_tmp));
         CHECK_NMI(nmi_synchronize(ctx));
         std::vector<uint8_t> img((size_t)W * H), frame((size_t)W * H);
         CHECK_HIP(hipMemcpy(img.data(), d_tmp, img.size(), hipMemcpyDeviceToHost));
@@ -149,7 +200,10 @@ int main(int argc, char **argv)
             }
         CHECK_HIP(hipMemcpy(d_frame, frame.data(), frame.size(), hipMemcpyHostToDevice));
     }
-    CHECK_NMI(nmi_level_create(ctx, d_xyz, d_red, (int64_t)red.size(), d_frame, 27, 27, p.rp.point_size, &p.level));
+    if (mesh)
+        CHECK_NMI(nmi_level_create_mesh(ctx, d_xyz, d_red, n_prims, tex, d_frame, 27, 27, &p.level));
+    else
+        CHECK_NMI(nmi_level_create(ctx, d_xyz, d_red, n_prims, d_frame, 27, 27, p.rp.point_size, &p.level));
 
     // 3^6 grid with the steps of ETH_small.yaml:83-88
     NmiSearchKernel initial(3, 3, 3, 3, 3, 3, 0.2f, 0.2f, 0.5f, 0.02f, 0.02f, 0.05f);
@@ -192,11 +246,13 @@ int main(int argc, char **argv)
         ok = ok && o.kernel.best[0] == out.kernel.best[0] && o.kernel.nmi == out.kernel.nmi;  // deterministic
     }
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    printf("%d keyframes, %d levels (27 renders of %zu points + 27 warps + 729-candidate search each): %.1f keyframes/s, %.1f levels/s, "
+    printf("%d keyframes, %d levels (27 renders of %lld %s + 27 warps + 729-candidate search each): %.1f keyframes/s, %.1f levels/s, "
            "%.3f ms per level\n",
-           keyframes, p.levels_run, red.size(), keyframes / dt, p.levels_run / dt, dt / p.levels_run * 1e3);
+           keyframes, p.levels_run, (long long)n_prims, mesh ? "textured triangles" : "points", keyframes / dt, p.levels_run / dt,
+           dt / p.levels_run * 1e3);
 
     nmi_level_destroy(p.level);
+    if (tex) nmi_texture_destroy(tex);
     (void)hipFree(d_xyz);
     (void)hipFree(d_red);
     (void)hipFree(d_frame);

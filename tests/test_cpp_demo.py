@@ -38,10 +38,12 @@ def test_demo_recovers_planted_offset():
 
 
 @pytest.mark.gpu
-def test_device_pipeline_recovers_planted_offset():
+@pytest.mark.parametrize("map_args", [[], ["--mesh"], ["--mesh", "60x40"]], ids=["cloud", "mesh-120k", "mesh-4800"])
+def test_device_pipeline_recovers_planted_offset(map_args):
+    """Point cloud (nmi_prop_RENDER 4) and textured mesh (nmi_prop_RENDER 1, the reference's default) as the map."""
     if not os.access(EXE_PIPELINE, os.X_OK):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    r = subprocess.run([EXE_PIPELINE, "20"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([EXE_PIPELINE, "20", *map_args], capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "PIPELINE OK" in r.stdout and "levels/s" in r.stdout

@@ -1,3 +1,3 @@
-mkdir -p $GRAFT_REPO_ROOT/gpurun_out/r03_r
-cd /tmp && export TMPDIR=/tmp
-for dbg in 0 1 2; do NMI_FRONT_DBG=$dbg rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r03_r/trace_$dbg -- python3 $GRAFT_REPO_ROOT/bench.py --config e2e --keyframes 20 > $GRAFT_REPO_ROOT/gpurun_out/r03_r/trace_$dbg.log 2>&1; grep -h "front_kernel\|resolve" $GRAFT_REPO_ROOT/gpurun_out/r03_r/trace_$dbg/*/*kernel_stats.csv | cut -d, -f1-4 | cut -c1-40,100-200; done
+mkdir -p $GRAFT_REPO_ROOT/gpurun_out/r03_s
+timeout -k 10 400 python3 -m pytest tests/test_cpp_demo.py -q -m gpu > gpurun_out/r03_s/tests.log 2>&1; echo rc=$? >> gpurun_out/r03_s/tests.log; tail -5 gpurun_out/r03_s/tests.log
+for a in "" "--mesh" "--mesh 60x40"; do ./examples/level_pipeline 200 $a | tail -3; done > gpurun_out/r03_s/level_pipeline.txt 2>&1; cat gpurun_out/r03_s/level_pipeline.txt
