@@ -371,12 +371,13 @@ int nmi_last_kernel_ms(nmi_ctx *ctx, float *h_ms);
                                   range, merged per row part: nmi_eval_pair = 8 x 4 = 32 workgroups; 4 with 8 row parts only).
                                   -1 (default): see NMI_OPT_SPLIT; 1: never; 2 / 4: that many when it exists and fits. */
 #define NMI_OPT_CONTENT_PATH 12 /* frames with few distinct intensities (posterised, thresholded, quantised): -1 (default)
-                                  automatic -- every 32nd search (every 256th once the answer has been the same for a while) is probed for the number of distinct intensities in its two
-                                  stacks (nr, nw), and while nr * nw <= NMI_OPT_FEWLEVELS_BINS searches go down the few-levels
+                                  automatic -- every search by the general kernel also counts the distinct intensities (bins) its
+                                  candidates' marginal histograms hold, (nr, nw), at no extra launch, and every few-levels search
+                                  probes its two stacks; while nr * nw <= NMI_OPT_FEWLEVELS_BINS searches go down the few-levels
                                   path (rank images + 32-bit replicated counters; csrc/nmi_fewlevels_kernel.hip; with fewer than
-                                  256 bins the count is of bins, and the background rule must be on); 0: never;
-                                  1: always try it first.  Every few-levels search probes its own stacks and falls back to
-                                  the general kernel on the device when they do not qualify: results never depend on it. */
+                                  256 bins the background rule must be on).  A change of content costs one search on the slower
+                                  path either way.  0: never; 1: always try it first.  Every few-levels search falls back to the
+                                  general kernel on the device when its stacks do not qualify: results never depend on it. */
 #define NMI_OPT_FEWLEVELS_BINS 13 /* largest nr * nw sent down the few-levels path (1..4096, default 4096) */
 #define NMI_OPT_STAMPS 9       /* profiling tools only: value = device pointer to uint64 [workgroups][8]; workgroups of the
                                   split kernel store wall-clock stamps (100 MHz) at their phase boundaries there; 0 = off */

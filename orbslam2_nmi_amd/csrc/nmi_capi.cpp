@@ -267,31 +267,23 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     // Few-levels path (nmi_fewlevels_kernel.hip).  The decision rests on what the most recent probe of a search's stacks
     // found (frames and renders of consecutive searches look alike); it is only a matter of speed, because the probe that
     // goes with every few-levels launch hands the search back to nmi_grid_kernel (gated launch below) when this
-    // search's stacks do not qualify.  While the hint says "ordinary content", every kProbeEvery-th search is probed, every
-    // 2 kProbeEvery-th ... kProbeEveryMax-th once probes keep confirming it.
-    bool few = false, probe_only = false;
+    // search's stacks do not qualify.
+    bool few = false;
     const bool few_eligible = !parts && a.vec_ok && (ctx->shift == 0 || p.use_bg) && ctx->hist_variant == 3 && ctx->phase_mask == 3 && !dbg_joint &&
                               !dbg_h1 && !dbg_h2 && !dbg_sums && !ctx->pair_renders && !ctx->dbg_stamps && ctx->content_path != 0;
     if (few_eligible) {
+        // What the most recent search found in its stacks (nr, nw), posted by the device: by the probe that goes with every
+        // few-levels launch, or by nmi_grid_kernel itself -- every general search counts the bins of its candidates'
+        // marginals on the way (publish_seen / post_seen), so a change of content shows after ONE search, with no extra launch.
         const unsigned long long posted = __atomic_load_n(ctx->level_post, __ATOMIC_ACQUIRE);
         if ((uint32_t)(posted >> 32) != ctx->level_seen) {
             ctx->level_seen = (uint32_t)(posted >> 32);
             const uint32_t joint = (uint32_t)((posted >> 16) & 0xFFFFu) * (uint32_t)(posted & 0xFFFFu);
-            const bool hint = joint > 0 && joint <= (uint32_t)ctx->fewlevels_bins;
-            if (hint != ctx->few_hint)
-                ctx->probe_interval = nmi_ctx::kProbeEvery;
-            else if (!hint && ctx->probe_interval < nmi_ctx::kProbeEveryMax)
-                ctx->probe_interval *= 2;  // confirmed once more: look less often
-            ctx->few_hint = hint;
+            ctx->few_hint = joint > 0 && joint <= (uint32_t)ctx->fewlevels_bins;
         }
         few = ctx->content_path == 1 || ctx->few_hint;
-        if (!few) {
-            probe_only = ctx->probe_wait == 0;
-            ctx->probe_wait = probe_only ? ctx->probe_interval - 1 : ctx->probe_wait - 1;
-        } else {
-            ctx->probe_wait = 0;  // back on ordinary content the first search is probed (it carries its own probe anyway)
-        }
     }
+    if (!parts && !few && ctx->hist_variant == 3 && ctx->content_path != 0) a.plan = ctx->d_plan;  // the search doubles as a probe
     if (few) {
         const size_t need = (size_t)(S_local + Wn) * (size_t)ctx->npix;
         if (need > ctx->rank_bytes) {
@@ -307,7 +299,7 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
         a.plan = ctx->d_plan;
     }
     if (ctx->profiling) NMI_HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
-    if (few || probe_only)
+    if (few)
         NMI_HIP_TRY(ctx, nmi::launch_levels(render_stack, S_local, warp_stack, Wn, ctx->npix, ctx->shift, ctx->d_plan, ctx->level_post, ++ctx->level_seq,
                                             (uint32_t)ctx->fewlevels_bins, few, ctx->stream));
     if (parts) {
@@ -564,6 +556,14 @@ int nmi_create(const nmi_params *params, nmi_ctx **out_ctx)
     *ctx->level_post = 0;
     if ((e = hipMalloc((void **)&ctx->d_plan, sizeof(nmi::LevelPlan))) != hipSuccess) return fail(e, "hipMalloc(level plan)");
     if ((e = hipMemsetAsync(ctx->d_plan, 0, sizeof(nmi::LevelPlan), ctx->stream)) != hipSuccess) return fail(e, "hipMemsetAsync(level plan)");
+    {
+        // where the general kernel's last workgroup posts what its search found (every search is a content probe)
+        unsigned long long *d_post = nullptr;
+        if ((e = hipHostGetDevicePointer((void **)&d_post, ctx->level_post, 0)) != hipSuccess) return fail(e, "hipHostGetDevicePointer(level post)");
+        if ((e = hipMemcpyAsync(&ctx->d_plan->seen_post, &d_post, sizeof d_post, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+            return fail(e, "hipMemcpyAsync(level post)");
+        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");  // (d_post is a local)
+    }
     if ((e = hipEventCreate(&ctx->ev_start)) != hipSuccess) return fail(e, "hipEventCreate");
     if ((e = hipEventCreate(&ctx->ev_stop)) != hipSuccess) return fail(e, "hipEventCreate");
     if ((e = nmi::launch_table(ctx->table, ctx->npix, ctx->stream)) != hipSuccess) return fail(e, "launch_table");
@@ -680,8 +680,6 @@ int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value)
         if (value < -1 || value > 1) return NMI_ERR_INVALID_ARGUMENT;
         ctx->content_path = (int)value;
         ctx->few_hint = false;
-        ctx->probe_wait = 0;
-        ctx->probe_interval = nmi_ctx::kProbeEvery;
         return NMI_OK;
     case NMI_OPT_FEWLEVELS_BINS:
         if (value < 1 || value > nmi::fewlevels_max_joint()) return NMI_ERR_INVALID_ARGUMENT;

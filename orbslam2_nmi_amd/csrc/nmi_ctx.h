@@ -93,10 +93,6 @@ struct nmi_ctx {
     bool few_hint = false;                // the last probe seen found nr * nw <= fewlevels_bins
     int content_path = -1;                // NMI_OPT_CONTENT_PATH: -1 automatic (hint), 0 nmi_grid_kernel only, 1 few-levels first
     int fewlevels_bins = 4096;            // NMI_OPT_FEWLEVELS_BINS: largest nr * nw sent down the few-levels path
-    // Automatic mode, hint "ordinary content": a search is probed when probe_wait reaches 0; the wait starts at
-    // kProbeEvery searches and doubles up to kProbeEveryMax each time a probe confirms the hint.
-    uint32_t probe_wait = 0, probe_interval = 32;
-    static constexpr uint32_t kProbeEvery = 32, kProbeEveryMax = 256;
     uint8_t *d_rank_stacks = nullptr;     // rank images of the search in flight: renders, then warps
     size_t rank_bytes = 0;
     int last_few = 0;                     // the most recent launch went down the few-levels path (it may have fallen back)

@@ -108,7 +108,8 @@ __device__ __forceinline__ void commit_score(const GridArgs &a, int p, int w, in
 // workgroup's maxes, so it is issued after they were performed; the workgroup that draws the last ticket therefore
 // reads the final key.  Nothing here needs a cache write-back: the key travels in atomics, and the mailbox is one
 // 8-byte store (key in bits 0..62, launch parity in bit 63 -- scores are non-negative floats, bit 63 is free).
-__device__ __forceinline__ void publish_winner(const GridArgs &a, unsigned long long prev_key)
+// Returns true in the workgroup that drew the last ticket.
+__device__ __forceinline__ bool publish_winner(const GridArgs &a, unsigned long long prev_key)
 {
     const unsigned int one = prev_key == ~0ull ? 2u : 1u;  // always 1 (a key never has all bits set)
     const unsigned int arrived = __hip_atomic_fetch_add(a.done, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -120,7 +121,9 @@ __device__ __forceinline__ void publish_winner(const GridArgs &a, unsigned long 
         if (a.mailbox)
             __hip_atomic_store(&a.mailbox->word, final_key | ((unsigned long long)(a.seq & 1u) << 63), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_SYSTEM);
+        return true;
     }
+    return false;
 }
 
 }  // namespace

@@ -26,6 +26,12 @@ struct LevelPlan {
     uint32_t mask[2][8];      // presence bits being merged by a probe (left 0)
     uint8_t rank_r[256], rank_w[256];    // intensity -> rank of its bin among the bins present (0 where absent)
     uint8_t level_r[256], level_w[256];  // rank -> bin
+    // Every search by nmi_grid_kernel is a probe as well: its workgroups OR the bins their candidates' marginal histograms hold
+    // into seen[] (word r * 16 + i, bit k: bin i + 16 k for k < 8, bin i + 16 (k - 8) + 128 above; r = 0 render, 1 frame) and the
+    // last workgroup counts them, posts (nr, nw) to *seen_post and leaves seen[] zero.
+    uint32_t seen[32];
+    uint32_t pad2[2];
+    unsigned long long *seen_post;       // pinned host word: (0x80000000 | a time stamp) << 32 | nr << 16 | nw
 };
 
 struct GridArgs {

@@ -513,6 +513,17 @@ __device__ __forceinline__ void final_phase(Lds &lds, const GridArgs &a, int lan
         lo[k] = a.table[cl[k]];
         hi[k] = a.table[ch[k]];
     }
+    if ((w == 0 || s == 0) && a.plan) {
+        // The search as its own content probe (NMI_OPT_CONTENT_PATH): which bins do the two marginals hold?  16 flags per lane
+        // of DPP rows 0 and 1, ORed into the plan's masks (LevelPlan::seen) while the table lookups above are in flight --
+        // fire-and-forget device atomics, issued as the search goes, not at its end (8,000 of them from all workgroups' exits
+        // into one cache line put 1.5 us on the end of every search).  Only the candidates of the grid's first row and first
+        // column do this: between them they show every render and every warp once.
+        uint32_t m = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m |= (cl[k] != 0u ? 1u << k : 0u) | (ch[k] != 0u ? 0x100u << k : 0u);
+        if (lane < 32 && m) __hip_atomic_fetch_or(const_cast<uint32_t *>(&a.plan->seen[lane]), m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (r == 2) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -529,6 +540,44 @@ __device__ __forceinline__ void final_phase(Lds &lds, const GridArgs &a, int lan
         }
     }
     if (lane == 0) commit_score(a, p, w, s, a1, a2, a3, prev_key);
+}
+
+// End of a workgroup of nmi_grid_kernel, by all of wavefront 0: publish_winner (nmi_device.h) plus the content probe's share.
+// The workgroup that draws the last ticket fetches the plan's bins-seen masks (final_phase ORs them in; it zeroes them for
+// the next search) in the same round trip as the final key, posts the winner first and then (nr, nw) to the pinned word
+// the context watches.  Nothing waits for the ORs of other workgroups: a straggling OR can cost a bin in this count or add
+// one to the next search's -- the count is a hint for the host's choice of kernels, every few-levels launch probes its own
+// stacks exactly.
+__device__ __forceinline__ void finish_search(const GridArgs &a, int lane, unsigned long long prev_key)
+{
+    LevelPlan *plan = const_cast<LevelPlan *>(a.plan);
+    uint32_t arrived = 0;
+    if (lane == 0) {
+        const unsigned int one = prev_key == ~0ull ? 2u : 1u;  // always 1; ties the ticket to this workgroup's maxes (publish_winner)
+        arrived = __hip_atomic_fetch_add(a.done, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (__builtin_amdgcn_readfirstlane(arrived) != gridDim.x - 1) return;
+    unsigned long long final_key = 0;
+    uint32_t bits = 0;
+    unsigned long long *post = nullptr;
+    if (lane == 0) final_key = __hip_atomic_load(a.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (plan && lane < 32) bits = __hip_atomic_exchange(&plan->seen[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (plan && lane == 0) post = plan->seen_post;  // (one round trip for the three of them)
+    if (lane == 0) {
+        __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.out_key) __hip_atomic_store(a.out_key, final_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (a.mailbox)
+            __hip_atomic_store(&a.mailbox->word, final_key | ((unsigned long long)(a.seq & 1u) << 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (plan) {
+        const uint32_t n = row_sum_16((uint32_t)__popc(bits));  // lanes 0 / 16: bins seen in the render / frame marginals
+        const uint32_t nw = (uint32_t)__shfl((int)n, 16, 64);
+        if (lane == 0 && post) {
+            // the word's upper half only has to differ from the previous post's: the 100 MHz clock serves (no counter to load)
+            const uint32_t stamp = 0x80000000u | (uint32_t)wall_clock64();
+            __hip_atomic_store(post, ((unsigned long long)stamp << 32) | ((unsigned long long)n << 16) | nw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // One candidate start to finish on the exact path (returning atomics + wrap bookkeeping + flat-region folding), all 16
@@ -674,7 +723,9 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void NMI_GRID_KERNEL_NAME(GridAr
         for (int o = exact_from; o < total; o += gridDim.x) exact_candidate<SHIFTED, !kZero0>(lds, a, tid, candidate_at(a, o), prev_key);
     }
 
-    if (tid == 0 && !(a.phase_mask & 16)) publish_winner(a, prev_key);  // bit 4: timing experiment without the protocol (no result)
+    if (wave == 0 && !(a.phase_mask & 16)) {  // bit 4: timing experiment without the protocol (no result)
+        finish_search(a, lane, prev_key);
+    }
 }
 
 #ifdef NMI_GRID_KERNEL_GATED

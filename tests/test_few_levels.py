@@ -128,8 +128,9 @@ def test_ordinary_content_falls_back_on_the_device(nmi):
 
 
 def test_automatic_mode_follows_the_content(nmi):
-    """Default options: the first search of a context is probed, posterised content moves the following searches to the
-    few-levels path, ordinary content moves them back (that search itself falls back on the device)."""
+    """Default options: every search by the general kernel is a content probe as well (its last workgroup posts the bins its
+    candidates' marginals held), so posterised content moves the searches to the few-levels path after ONE general search,
+    and ordinary content moves them back after one (that search itself falls back on the device)."""
     from oracle import binding as oc
     from orbslam2_nmi_amd import synthetic as sy
     w, h = 320, 240
@@ -138,7 +139,7 @@ def test_automatic_mode_follows_the_content(nmi):
     pos = (quantise(nat[0], 8), quantise(nat[1], 8))
     with oc.rounded():
         want = {id(nat): oc.search_grid(*nat, threads=16), id(pos): oc.search_grid(*pos, threads=16)}
-    seq = [(pos, False), (pos, True), (pos, True), (nat, False), (nat, False), (pos, None), (pos, None)]
+    seq = [(pos, False), (pos, True), (pos, True), (nat, False), (nat, False), (pos, False), (pos, True), (nat, False), (pos, False), (pos, True)]
     with nmi.NmiContext(w, h) as ctx:
         ratings = torch.zeros((9, 9), dtype=torch.float32, device="cuda")
         d = {id(nat): (dev(nat[0]), dev(nat[1])), id(pos): (dev(pos[0]), dev(pos[1]))}

@@ -49,18 +49,44 @@ cases = {
 ctx = nmi.NmiContext(W, H)
 ctx.set_profiling(True)
 out = []
+dev = {}
 for name, (rs_h, ws_h) in cases.items():
-    rs, ws = torch.from_numpy(np.ascontiguousarray(rs_h)).cuda(), torch.from_numpy(np.ascontiguousarray(ws_h)).cuda()
-    ratings = torch.empty((Wn, S), dtype=torch.float32, device="cuda")
+    dev[name] = (torch.from_numpy(np.ascontiguousarray(rs_h)).cuda(), torch.from_numpy(np.ascontiguousarray(ws_h)).cuda())
+ratings = torch.empty((Wn, S), dtype=torch.float32, device="cuda")
+
+
+def searches(name, n):
+    rs, ws = dev[name]
     t = []
-    for i in range(300):  # default options: the path follows the content within 32 ... 256 searches (NMI_OPT_CONTENT_PATH -1)
-        r = ctx.search_grid(rs, ws, ratings=ratings)
+    for _ in range(n):
+        ctx.search_grid(rs, ws, ratings=ratings)
         t.append(ctx.last_kernel_ms() * 1e3)
+    return t
+
+
+for name in cases:
+    t = searches(name, 60)  # default options: the path follows the content (NMI_OPT_CONTENT_PATH -1)
     us, first = float(np.median(t[-10:])), float(t[0])
     info = ctx.last_content()
     path = "few-levels (%d x %d)" % (info["nr"], info["nw"]) if info["few_levels"] else "general"
     out.append({"content": name, "kernel_us": round(us, 1), "evals_per_s": round(S * Wn / us * 1e6), "path": path,
                 "first_search_us": round(first, 1)})
     print(f"{name:42s} {us:8.1f} us  {S * Wn / us:6.2f} M evals/s   {path}   (first search after the change of content {first:.1f} us)", flush=True)
+
+# Transitions: a stream whose content changes.  How many searches, and how many microseconds, until the steady path's time
+# (within 10 % of the content's steady-state time above) is reached?  Every general search is a content probe (its last
+# workgroup posts the bins it found), every few-levels search carries its own probe: one search either way.
+steady = {o["content"]: o["kernel_us"] for o in out}
+transitions = []
+print("\ntransitions (searches until within 10 % of the steady time; times of the first searches after the switch, us)")
+for a, b in (("default (smooth scene + noise)", "posterised to 4 levels"), ("posterised to 4 levels", "default (smooth scene + noise)"),
+             ("default (smooth scene + noise)", "posterised to 16 levels"), ("posterised to 16 levels", "default (smooth scene + noise)"),
+             ("uniform noise", "constant images"), ("constant images", "uniform noise")):
+    searches(a, 20)
+    t = searches(b, 12)
+    slow = next((i for i, v in enumerate(t) if v <= 1.1 * steady[b]), len(t))
+    extra = float(sum(v - steady[b] for v in t[:slow]))
+    transitions.append({"from": a, "to": b, "slow_searches": slow, "extra_us": round(extra, 1), "first_us": [round(v, 1) for v in t[:4]]})
+    print(f"{a:34s} -> {b:34s} {slow} slow search(es), {extra:7.1f} us lost   first four: {[round(v, 1) for v in t[:4]]}", flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "content_sensitivity.json"), "w"), indent=1)
+json.dump({"steady": out, "transitions": transitions}, open(os.path.join(ROOT, "gpurun_out", "content_sensitivity.json"), "w"), indent=1)
