@@ -222,6 +222,29 @@ def timed_region(fn, dist):
     return elapsed, out
 
 
+def call_site_rate(timeout_s=120):
+    """The reference's UNCHANGED per-candidate call site (src/Tracking.cc:1886-1894: one blocking
+    CUDAF::NMIWithCuda_noMask per candidate, here through host/cudaf_shim.hpp) measured by the C++ program
+    examples/relocalize_demo, part C, run as a CHILD process after the timed region -- never inside it."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "examples", "relocalize_demo")
+    if not os.access(exe, os.X_OK):
+        return {"error": "examples/relocalize_demo is not built (python -c 'import __graft_entry__ as g; g.build()')"}
+    try:
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": "examples/relocalize_demo timed out"}
+    m1, m2 = re.search(r"SHIM_EVALS_PER_S (\d+)", r.stdout), re.search(r"SHIM_BATCHED_EVALS_PER_S (\d+)", r.stdout)
+    if r.returncode != 0 or not m1 or not m2:
+        return {"error": f"examples/relocalize_demo failed (rc {r.returncode})"}
+    rate = float(m1.group(1))
+    return {"evals_per_s": rate, "us_per_call": 1e6 / rate, "batched_evals_per_s": float(m2.group(1)),
+            "what": "640x480, one blocking CUDAF::NMIWithCuda_noMask per candidate through the identical-signature shim "
+                    "(examples/relocalize_demo part C, child process after the timed region); batched = BeginBatch / Flush around the warp loop",
+            "target_evals_per_s": 50000}
+
+
 def load_pmc_lds():
     """LDS-side counters of the dominant kernel from the committed PMC profile (profiles/pmc_lds.json), or None."""
     try:
@@ -493,6 +516,7 @@ def main():
     ap.add_argument("--clock-warmup-ms", type=float, default=200.0,
                     help="untimed searches for this long before the warm-up steps, to bring the device to its sustained clock (0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-call-site", action="store_true", help="skip the call_site key (examples/relocalize_demo as a child process)")
     ap.add_argument("--blocking", action="store_true", help="latency mode: one blocking search per step")
     ap.add_argument("--streams", type=int, default=1,
                     help="searches kept in flight in throughput mode (one context + stream each); 2 fills the idle CUs of the "
@@ -740,6 +764,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_budget, args.cpu_threads)
+        if world == 1 and not args.no_call_site and args.config == "c2":
+            out["call_site"] = call_site_rate()
         print(json.dumps(out))
     for c in ctxs:
         c.close()

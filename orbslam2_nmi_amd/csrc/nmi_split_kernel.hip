@@ -311,6 +311,46 @@ __device__ __forceinline__ void histogram_split(uint32_t *joint, const GridArgs 
     }
 }
 
+// A pixel range short enough for a lane to hold ALL its chunks at once (at most kShortChunks pairs of 16 bytes: one pair of a
+// 640x480 frame cut into 4 ranges is 4.7 chunks per lane): the loads are issued together, before the workgroup has even
+// cleared its counters, and their latency -- the histogram phase of such a range is three dependent L2 / HBM round trips
+// in the pipelined loop -- is paid once, under the clear and its barrier.
+constexpr int kShortChunks = 5;
+struct ShortRange {
+    uint4 r[kShortChunks], w[kShortChunks];
+    int first, nchunks;
+    bool on;
+};
+
+__device__ __forceinline__ void load_short(ShortRange &sr, const GridArgs &a, const uint8_t *__restrict__ render, const uint8_t *__restrict__ warped,
+                                           int tid, int pix_part, int pix_parts)
+{
+    const int all_chunks = a.npix >> 4, last = all_chunks - 1;
+    split_range(all_chunks, pix_part, pix_parts, sr.first, sr.nchunks);
+#pragma unroll
+    for (int k = 0; k < kShortChunks; ++k) {
+        const int c = sr.first + tid + k * kBlock;
+        sr.w[k] = load_frame_chunk(warped, c, last);
+        sr.r[k] = load_render_chunk(a, render, c, last);
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void add_short(uint32_t *joint, const ShortRange &sr, const GridArgs &a, int tid, int part)
+{
+    constexpr uint32_t kRows = kBins / K;
+    const uint32_t xorpat = (uint32_t)part * kRows * 0x01010101u;
+    const bool fold = !(a.phase_mask & 4);
+#pragma unroll
+    for (int k = 0; k < kShortChunks; ++k) {
+        if (sr.first + tid + k * kBlock >= sr.nchunks) continue;
+        if (fold && __builtin_expect(flat_hint(sr.r[k], sr.w[k]), 0))
+            add_chunk_careful<K>(joint, sr.r[k], sr.w[k], xorpat, part);
+        else
+            add_chunk_split<K>(sr.r[k], sr.w[k], xorpat);
+    }
+}
+
 // Decode of this part's rows: counters -> per-bin terms (ComputeEntropyKernel, NMI.cu:242-263, through the per-count
 // table) -> row trees (AddvectorParwiseMidKernel, NMI.cu:270-287).  Same lane / word ownership as decode_phase in
 // nmi_kernels.hip: a wavefront takes 4 rows per pass, one per 16-lane DPP row; lane i of a row owns the bins
@@ -562,6 +602,23 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_split_kernel(GridArgs a
         total = a.S_local * a.Wn;
         phase_mask = a.phase_mask;
     }
+    ShortRange sr;
+    sr.on = false;
+    int short_part = 0;
+    if (FAST && P > 1 && (phase_mask & 1)) {  // (pixel ranges: the one-pair and few-pair launches, where latency is the whole cost)
+        const GridArgs a = fresh();
+        const int units0 = split_workgroups(total, K, P);
+        int p0, part0, pix0;
+        split_unit((int)blockIdx.x, total, K, P, p0, part0, pix0);
+        const int per_part = ((a.npix >> 4) + P - 1) / P;
+        if (a.vec_ok && (int)blockIdx.x < units0 && p0 < total && per_part <= kShortChunks * kBlock) {
+            const int w0 = p0 / a.S_local, s0 = p0 - w0 * a.S_local;
+            load_short(sr, a, a.pair_renders ? a.pair_renders[p0] : a.render_stack + (size_t)s0 * a.npix,
+                       a.pair_warps ? a.pair_warps[p0] : a.warp_stack + (size_t)w0 * a.npix, tid, pix0, P);
+            sr.on = true;
+            short_part = part0;
+        }
+    }
     {
         uint4 *j4 = reinterpret_cast<uint4 *>(lds.joint);
         const uint4 z = {0, 0, 0, 0};
@@ -571,6 +628,11 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_split_kernel(GridArgs a
     // add_chunk_split addresses the counters from LDS address 0
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds.joint != 0u) __builtin_trap();
     __syncthreads();
+    const bool hist_done = sr.on;
+    if (sr.on) {  // this workgroup's first unit: its chunks are already in registers (and die here)
+        const GridArgs a = fresh();
+        add_short<K>(lds.joint, sr, a, tid, short_part);
+    }
 
     const int units = split_workgroups(total, K, P);
     unsigned long long prev_key = 0;
@@ -580,7 +642,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_split_kernel(GridArgs a
         if (p >= total) continue;  // workgroup-uniform
 
         stamp(1);
-        if (phase_mask & 1) {
+        if ((phase_mask & 1) && !(hist_done && u == (int)blockIdx.x)) {
             const GridArgs a = fresh();
             const int w = p / a.S_local, s = p - w * a.S_local;
             histogram_split<K, FAST>(lds.joint, a, a.pair_renders ? a.pair_renders[p] : a.render_stack + (size_t)s * a.npix,

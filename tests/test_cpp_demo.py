@@ -30,10 +30,11 @@ def test_demo_recovers_planted_offset():
     assert "DEMO OK" in r.stdout and "NmiKernel:" in r.stdout
     # part C of the demo: the reference's unchanged per-candidate call site (src/Tracking.cc:1886-1894) through the shim,
     # one blocking call per candidate at 640x480.  BASELINE.json's target for the path is 50,000 evals/s; measured
-    # 49-51 k on MI355X boxes (profiles/r02_split/shim_rate.txt), the floor asserted here leaves room for a slow box.
+    # 50.6-53.1 k box to box in round 2 and 52.5-52.8 k in round 3 (profiles/r03_b/shim_rate.txt; bench.py reports the figure
+    # of the box it runs on as "call_site").  The floor asserted here leaves room for a slow box and a busy host core.
     rate = float(re.search(r"SHIM_EVALS_PER_S (\d+)", r.stdout).group(1))
     batched = float(re.search(r"SHIM_BATCHED_EVALS_PER_S (\d+)", r.stdout).group(1))
-    assert rate >= 42000, rate
+    assert rate >= 46000, rate
     assert batched >= 3 * rate, (rate, batched)
 
 

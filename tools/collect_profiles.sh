@@ -15,11 +15,11 @@ python3 bench.py --config e2e > "$OUT/bench_e2e.json" 2>> "$OUT/bench.err" || ex
 python3 bench.py --config c3 --steps 300 --cpu-budget 6 > "$OUT/bench_c3.json" 2>> "$OUT/bench.err" || exit 1
 python3 bench.py --config c4 --steps 300 --cpu-budget 6 > "$OUT/bench_c4.json" 2>> "$OUT/bench.err" || exit 1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --no-cpu-baseline > "$OUT/trace.log" 2>&1 || exit 1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" --steps 20 --warmup 2 --no-cpu-baseline > "$OUT/pmc_fetch.log" 2>&1 || exit 1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$ROOT/bench.py" --steps 20 --warmup 2 --no-cpu-baseline > "$OUT/pmc_write.log" 2>&1 || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c3" -- python3 "$ROOT/bench.py" --config c3 --steps 300 --no-cpu-baseline > "$OUT/trace_c3.log" 2>&1 || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c4" -- python3 "$ROOT/bench.py" --config c4 --steps 300 --no-cpu-baseline > "$OUT/trace_c4.log" 2>&1 || exit 1
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU --output-format csv -d "$OUT/pmc_lds" -- python3 "$ROOT/bench.py" --steps 20 --warmup 2 --no-cpu-baseline > "$OUT/pmc_lds.log" 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-call-site > "$OUT/trace.log" 2>&1 || exit 1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" --steps 20 --warmup 2 --no-cpu-baseline --no-call-site > "$OUT/pmc_fetch.log" 2>&1 || exit 1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$ROOT/bench.py" --steps 20 --warmup 2 --no-cpu-baseline --no-call-site > "$OUT/pmc_write.log" 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c3" -- python3 "$ROOT/bench.py" --config c3 --steps 300 --no-cpu-baseline --no-call-site > "$OUT/trace_c3.log" 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c4" -- python3 "$ROOT/bench.py" --config c4 --steps 300 --no-cpu-baseline --no-call-site > "$OUT/trace_c4.log" 2>&1 || exit 1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU --output-format csv -d "$OUT/pmc_lds" -- python3 "$ROOT/bench.py" --steps 20 --warmup 2 --no-cpu-baseline --no-call-site > "$OUT/pmc_lds.log" 2>&1 || exit 1
 cd "$ROOT"
 python3 tools/summarize_profiles.py "$OUT"

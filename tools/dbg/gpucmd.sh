@@ -1,13 +1,4 @@
-mkdir -p $GRAFT_REPO_ROOT/gpurun_out/r03_w
-for rep in 1 2 3; do
-  for v in before varA; do NMI_HIP_LIBRARY=$GRAFT_REPO_ROOT/orbslam2_nmi_amd/lib/libnmi_hip_$v.so python3 bench.py --no-cpu-baseline > gpurun_out/r03_w/${v}_$rep.json 2>>gpurun_out/r03_w/err.log; done
-  python3 bench.py --no-cpu-baseline > gpurun_out/r03_w/after_$rep.json 2>>gpurun_out/r03_w/err.log
-done
-python3 - <<'PY'
-import json
-for rep in (1,2,3):
-    for w in ("before","varA","after"):
-        d=json.load(open(f"gpurun_out/r03_w/{w}_{rep}.json"))
-        print(rep, w, round(d["value"]/1e6,3), "M evals/s; kernel us", round(d["roofline"]["kernel_ms"]*1e3,2), "blocking call ms", round(d["blocking_call_ms"],4))
-PY
-python3 tools/content_sensitivity.py 2>&1 | tail -8
+mkdir -p $GRAFT_REPO_ROOT/gpurun_out/r03_x
+timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py -q -m gpu -x > gpurun_out/r03_x/tests.log 2>&1; echo rc=$? >> gpurun_out/r03_x/tests.log; tail -3 gpurun_out/r03_x/tests.log
+for i in 1 2 3; do ./examples/relocalize_demo | grep "shim call site"; done > gpurun_out/r03_x/shim_rate.txt; cat gpurun_out/r03_x/shim_rate.txt
+python3 tools/split_stamps.py 1 1 8 3 4 > gpurun_out/r03_x/split_stamps_pair_8x4.txt 2>&1; tail -9 gpurun_out/r03_x/split_stamps_pair_8x4.txt
