@@ -562,6 +562,9 @@ int nmi_create(const nmi_params *params, nmi_ctx **out_ctx)
         if ((e = hipHostGetDevicePointer((void **)&d_post, ctx->level_post, 0)) != hipSuccess) return fail(e, "hipHostGetDevicePointer(level post)");
         if ((e = hipMemcpyAsync(&ctx->d_plan->seen_post, &d_post, sizeof d_post, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
             return fail(e, "hipMemcpyAsync(level post)");
+        const uint32_t max_joint = (uint32_t)ctx->fewlevels_bins;
+        if ((e = hipMemcpyAsync(&ctx->d_plan->seen_max_joint, &max_joint, sizeof max_joint, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+            return fail(e, "hipMemcpyAsync(level plan)");
         if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");  // (d_post is a local)
     }
     if ((e = hipEventCreate(&ctx->ev_start)) != hipSuccess) return fail(e, "hipEventCreate");
@@ -680,10 +683,24 @@ int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value)
         if (value < -1 || value > 1) return NMI_ERR_INVALID_ARGUMENT;
         ctx->content_path = (int)value;
         ctx->few_hint = false;
+        {   // the device posts changes of its verdict only: start it from "not few" as well (blocking: a local is copied)
+            DeviceGuard guard(ctx->device);
+            const uint32_t zero = 0;
+            NMI_HIP_TRY(ctx, hipMemcpyAsync(&ctx->d_plan->seen_state, &zero, sizeof zero, hipMemcpyHostToDevice, ctx->stream));
+            NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
         return NMI_OK;
     case NMI_OPT_FEWLEVELS_BINS:
         if (value < 1 || value > nmi::fewlevels_max_joint()) return NMI_ERR_INVALID_ARGUMENT;
         ctx->fewlevels_bins = (int)value;
+        {
+            DeviceGuard guard(ctx->device);
+            const uint32_t max_joint = (uint32_t)value, zero = 0;
+            NMI_HIP_TRY(ctx, hipMemcpyAsync(&ctx->d_plan->seen_max_joint, &max_joint, sizeof max_joint, hipMemcpyHostToDevice, ctx->stream));
+            NMI_HIP_TRY(ctx, hipMemcpyAsync(&ctx->d_plan->seen_state, &zero, sizeof zero, hipMemcpyHostToDevice, ctx->stream));
+            NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->few_hint = false;
+        }
         return NMI_OK;
     case NMI_OPT_WORKGROUPS:
         if (value < 0 || value > (1 << 20)) return NMI_ERR_INVALID_ARGUMENT;

@@ -30,8 +30,10 @@ struct LevelPlan {
     // into seen[] (word r * 16 + i, bit k: bin i + 16 k for k < 8, bin i + 16 (k - 8) + 128 above; r = 0 render, 1 frame) and the
     // last workgroup counts them, posts (nr, nw) to *seen_post and leaves seen[] zero.
     uint32_t seen[32];
-    uint32_t pad2[2];
-    unsigned long long *seen_post;       // pinned host word: (0x80000000 | a time stamp) << 32 | nr << 16 | nw
+    uint32_t seen_state;                 // 1: the last post said "few levels" (nr * nw <= seen_max_joint), 0: it said not (or none yet)
+    uint32_t seen_max_joint;             // NMI_OPT_FEWLEVELS_BINS, for that comparison
+    unsigned long long *seen_post;       // pinned host word: (0x80000000 | a time stamp) << 32 | nr << 16 | nw -- written only when
+                                         // the verdict CHANGES (a store to host memory holds the kernel's end back by a PCIe trip)
 };
 
 struct GridArgs {
