@@ -947,7 +947,8 @@ hipError_t launch_render_mesh(const float *xyz, const float *uv, long long ntri,
         if (ntri > 0) {
             ClipItem *clipq = static_cast<ClipItem *>(w.clip_queue);
             // shares of the views: aim at ~half a million lanes
-            long long shares = (500000 + ntri - 1) / ntri;
+            static const long long lanes_wanted = getenv("NMI_MESH_LANES") ? atoll(getenv("NMI_MESH_LANES")) : 500000;
+            long long shares = (lanes_wanted + ntri - 1) / ntri;
             shares = shares < 1 ? 1 : (shares > views ? views : shares);
             hipLaunchKernelGGL(nmi_mesh_bin_kernel, dim3((unsigned)(wf.blocks + ((ntri + 255) / 256) * shares)), dim3(256), 0, stream, xyz, uv, ntri,
                                mvps + (size_t)s0 * 16, views, width, height, g, clipq, w.clip_state, clip_cap, (int)shares, wf);
