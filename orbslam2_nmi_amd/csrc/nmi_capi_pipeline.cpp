@@ -26,11 +26,13 @@ struct nmi_level {
     void *d_packed = nullptr;                   // point cloud: the level's own packed copy of the cloud (16-byte records + wavefront boxes)
     nmi::MeshWork mesh;                         // textured mesh: the renderer's work area (kept clean by the renderer itself)
     bool is_mesh = false;
+    bool fused_points = false;                  // point cloud, one chain of kernels, double-buffered anchors
     float *d_mvps = nullptr, *h_mvps = nullptr, *d_coeffs = nullptr, *h_coeffs = nullptr;
     int *d_order = nullptr;
     float *d_ratings = nullptr;                 // [Wn][S] rating table of the latest replay
     unsigned long long *d_key = nullptr, *h_key = nullptr;
     unsigned int *d_done = nullptr;
+    uint32_t *d_epoch = nullptr;                // replay parity of the double-buffered anchors (fused point-cloud form)
     hipStream_t side = nullptr;                 // forked capture branch (warp)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipGraph_t graph = nullptr;
@@ -46,7 +48,7 @@ int nmi_level_destroy(nmi_level *lv)
     (void)hipStreamSynchronize(lv->ctx->stream);
     if (lv->exec) (void)hipGraphExecDestroy(lv->exec);
     if (lv->graph) (void)hipGraphDestroy(lv->graph);
-    void *dev[] = {lv->d_packed, lv->d_renders, lv->d_warps, lv->d_zbuf, lv->d_mvps, lv->d_coeffs, lv->d_order, lv->d_key, lv->d_done, lv->d_ratings};
+    void *dev[] = {lv->d_packed, lv->d_renders, lv->d_warps, lv->d_zbuf, lv->d_mvps, lv->d_coeffs, lv->d_order, lv->d_key, lv->d_done, lv->d_ratings, lv->d_epoch};
     for (void *q : dev)
         if (q) (void)hipFree(q);
     void *host[] = {lv->h_mvps, lv->h_coeffs, lv->h_key};
@@ -122,8 +124,16 @@ static int level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_attr, i
     if (tex) {
         if (mesh_work_alloc(ctx, S, &lv->mesh) != NMI_OK) e = hipErrorOutOfMemory;
     } else {
-        ok(hipMalloc((void **)&lv->d_zbuf, nmi::render_zbuf_words(S, p.width, p.height, lv->size) * sizeof(uint32_t)));
+        // Anchors: two buffers when the level runs as one chain of kernels (the front kernel of replay k clears the buffer of
+        // replay k + 1); the classic form keeps one and clears it in its prep node.
+        lv->fused_points = nmi::level_front_eligible(d_frame, nullptr, p.width, S) && n_points > 0 && nmi::level_points_double_buffered(p.width, lv->size);
+        const size_t words = lv->fused_points ? 2 * nmi::level_zbuf_pair_words(S, p.width, p.height, lv->size)
+                                              : nmi::render_zbuf_words(S, p.width, p.height, lv->size);
+        ok(hipMalloc((void **)&lv->d_zbuf, words * sizeof(uint32_t)));
+        ok(hipMalloc((void **)&lv->d_epoch, sizeof(uint32_t)));
         ok(hipMalloc(&lv->d_packed, nmi::cloud_pack_bytes(n_points, nullptr) + 16));
+        if (e == hipSuccess) ok(hipMemsetAsync(lv->d_zbuf, 0xFF, words * sizeof(uint32_t), ctx->stream));
+        if (e == hipSuccess) ok(hipMemsetAsync(lv->d_epoch, 0, sizeof(uint32_t), ctx->stream));
         if (e == hipSuccess) ok(nmi::launch_cloud_pack(d_xyz, d_red, n_points, lv->d_packed, ctx->stream));
     }
     ok(hipMalloc((void **)&lv->d_mvps, (size_t)S * 16 * sizeof(float)));
@@ -187,10 +197,11 @@ static int level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_attr, i
     if (e == hipSuccess && ok(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal))) {
         // (mesh: nothing to clear -- the renderer leaves its work area clean)
         ok(nmi::launch_level_prep(hd_mvps, lv->d_mvps, S * 16, hd_coeffs, lv->d_coeffs, Wn * 9, lv->d_key, lv->d_zbuf,
-                                  tex ? 0 : nmi::render_zbuf_words(S, p.width, p.height, lv->size), st));
+                                  (tex || lv->fused_points) ? 0 : nmi::render_zbuf_words(S, p.width, p.height, lv->size), st,
+                                  lv->fused_points ? lv->d_epoch : nullptr));
         // One chain of kernels when the warp blocks can ride along with the render's first kernel (the usual case: frame rows
         // 16-byte aligned); otherwise the warp kernel runs on a forked branch beside the render.
-        const bool fused = nmi::level_front_eligible(d_frame, lv->d_warps, p.width, S) && n_points > 0;
+        const bool fused = tex ? (nmi::level_front_eligible(d_frame, lv->d_warps, p.width, S) && n_points > 0) : lv->fused_points;
         if (!fused) {
             ok(hipEventRecord(lv->ev_fork, st));
             ok(hipStreamWaitEvent(lv->side, lv->ev_fork, 0));
@@ -202,8 +213,8 @@ static int level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_attr, i
                                        (int)(ctx->tile_queue_limit < 511 ? ctx->tile_queue_limit : 511), ctx->clip_queue_limit, lv->d_renders,
                                        p.width, p.height, st, fused ? d_frame : nullptr, lv->d_coeffs, lv->d_warps, Wn));
         else if (fused)
-            ok(nmi::launch_level_front_points(lv->d_packed, n_points, lv->d_mvps, S, lv->d_zbuf, lv->d_renders, p.width, p.height, lv->size,
-                                              d_frame, lv->d_coeffs, lv->d_warps, Wn, st));
+            ok(nmi::launch_level_front_points(lv->d_packed, n_points, lv->d_mvps, S, lv->d_zbuf, lv->d_epoch, lv->d_renders, p.width, p.height,
+                                              lv->size, d_frame, lv->d_coeffs, lv->d_warps, Wn, st));
         else
             ok(nmi::launch_render_points(d_xyz, d_red, n_points, lv->d_mvps, S, lv->d_zbuf, lv->d_renders, p.width, p.height, lv->size, st,
                                          /*clear_first=*/false));

@@ -172,10 +172,12 @@ hipError_t sort_records_morton(const float *a, int na, int verts, const float *b
 size_t cloud_pack_bytes(long long npoints, size_t *boxes_offset);
 hipError_t launch_cloud_pack(const float *xyz, const float *red, long long npoints, void *packed, hipStream_t stream);
 bool level_front_eligible(const void *frame, const void *warps, int width, int S);
-hipError_t launch_level_front_points(const void *packed, long long npoints, const float *mvps, int S, uint32_t *zbuf, uint8_t *out,
-                                     int width, int height, int size, const uint8_t *frame, const float *coeffs, uint8_t *warps, int Wn,
-                                     hipStream_t stream);
+bool level_points_double_buffered(int width, int size);  // the fused front kernel's form of the anchors: two buffers, cleared in turn
+size_t level_zbuf_pair_words(int S, int width, int height, int size);
+hipError_t launch_level_front_points(const void *packed, long long npoints, const float *mvps, int S, uint32_t *zbuf /* two buffers */,
+                                     const uint32_t *epoch, uint8_t *out, int width, int height, int size, const uint8_t *frame,
+                                     const float *coeffs, uint8_t *warps, int Wn, hipStream_t stream);
 hipError_t launch_level_prep(const float *h_mvps, float *d_mvps, int n_mvps, const float *h_coeffs, float *d_coeffs, int n_coeffs,
-                             unsigned long long *key, uint32_t *zbuf, size_t nz, hipStream_t stream);
+                             unsigned long long *key, uint32_t *zbuf, size_t nz, hipStream_t stream, uint32_t *epoch = nullptr);
 
 }  // namespace nmi

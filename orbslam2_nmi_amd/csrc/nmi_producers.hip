@@ -120,13 +120,14 @@ __global__ __launch_bounds__(256) void nmi_zbuf_clear_kernel(uint32_t *zbuf, siz
 // from the caller's pinned (device-mapped) buffers.
 __global__ __launch_bounds__(256) void nmi_level_prep_kernel(const float *__restrict__ h_mvps, float *__restrict__ d_mvps, int n_mvps,
                                                              const float *__restrict__ h_coeffs, float *__restrict__ d_coeffs, int n_coeffs,
-                                                             unsigned long long *key, uint32_t *zbuf, size_t nz)
+                                                             unsigned long long *key, uint32_t *zbuf, size_t nz, uint32_t *epoch)
 {
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
     if (blockIdx.x == 0) {
         for (int i = threadIdx.x; i < n_mvps; i += blockDim.x) d_mvps[i] = h_mvps[i];
         for (int i = threadIdx.x; i < n_coeffs; i += blockDim.x) d_coeffs[i] = h_coeffs[i];
         if (threadIdx.x == 0) *key = 0ull;
+        if (threadIdx.x == 0 && epoch) *epoch = *epoch + 1u;  // this replay's anchor buffer: zbuf pair [epoch & 1] (nmi_level_front_kernel)
     }
     uint4 *z4 = reinterpret_cast<uint4 *>(zbuf);
     const uint4 ones = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
@@ -135,10 +136,10 @@ __global__ __launch_bounds__(256) void nmi_level_prep_kernel(const float *__rest
 }
 
 hipError_t launch_level_prep(const float *h_mvps, float *d_mvps, int n_mvps, const float *h_coeffs, float *d_coeffs, int n_coeffs,
-                             unsigned long long *key, uint32_t *zbuf, size_t nz, hipStream_t stream)
+                             unsigned long long *key, uint32_t *zbuf, size_t nz, hipStream_t stream, uint32_t *epoch)
 {
     hipLaunchKernelGGL(nmi_level_prep_kernel, dim3(nz ? 2048 : 1), dim3(256), 0, stream, h_mvps, d_mvps, n_mvps, h_coeffs, d_coeffs, n_coeffs, key,
-                       zbuf, nz);
+                       zbuf, nz, epoch);
     return hipGetLastError();
 }
 
@@ -310,18 +311,31 @@ __global__ __launch_bounds__(256) void nmi_splat_kernel(const float *__restrict_
 
 // The front kernel of a captured point-cloud level: its first `warp_blocks` workgroups make the warp stack
 // (nmi_warp_device.h), the others splat the packed cloud -- one kernel node instead of a fork and a join in the graph.
+// The anchors are double-buffered by replay parity (*epoch, bumped by the prep node): this replay splats into buffer
+// epoch & 1 -- cleared by the PREVIOUS replay's front kernel -- and its last `clear_blocks` workgroups clear the other one for
+// the next replay.  The 44 MB of stores ride under a kernel that leaves the HBM idle (it is bound by per-wavefront latency
+// chains) instead of making a 9 us clear pass at the head of every level.
 __global__ __launch_bounds__(256) void nmi_level_front_kernel(PackedCloud pc, long long npoints, const float *__restrict__ mvps, int views,
-                                                              uint32_t *__restrict__ zbuf, int width, int height, int size, int stride,
+                                                              uint32_t *__restrict__ zbuf, size_t pair_words, const uint32_t *__restrict__ epoch,
+                                                              int width, int height, int size, int stride,
                                                               const uint8_t *__restrict__ frame, const float *__restrict__ coeffs,
-                                                              uint8_t *__restrict__ warps, int warp_blocks)
+                                                              uint8_t *__restrict__ warps, int warp_blocks, int splat_blocks, int clear_blocks)
 {
     if ((int)blockIdx.x < warp_blocks) {
         warp_lds_block_linear(frame, coeffs, warps, width, height, (int)blockIdx.x, (int)threadIdx.x);
         return;
     }
+    const uint32_t parity = *epoch & 1u;
     const long long b = (long long)blockIdx.x - warp_blocks;
-    splat_wave<true>(nullptr, nullptr, pc, npoints, mvps, views, zbuf, width, height, size, stride, (b * 256 + threadIdx.x) >> 6,
-                     (int)(threadIdx.x & 63));
+    if (b < splat_blocks) {
+        splat_wave<true>(nullptr, nullptr, pc, npoints, mvps, views, zbuf + (size_t)parity * pair_words, width, height, size, stride,
+                         (b * 256 + threadIdx.x) >> 6, (int)(threadIdx.x & 63));
+        return;
+    }
+    uint4 *other = reinterpret_cast<uint4 *>(zbuf + (size_t)(parity ^ 1u) * pair_words);  // (pair_words is a multiple of 4)
+    const uint4 ones = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    const size_t n4 = pair_words / 4, first = (size_t)(b - splat_blocks) * 256 + threadIdx.x, step = (size_t)clear_blocks * 256;
+    for (size_t i = first; i < n4; i += step) other[i] = ones;
 }
 
 // Resolve.  A lane takes a strip of four horizontally adjacent output pixels x kResolveRows rows and slides down it: every
@@ -334,9 +348,10 @@ constexpr int kResolveRows = 8;
 
 template <int SIZE>
 __global__ __launch_bounds__(256) void nmi_zbuf_resolve_fast_kernel(const uint32_t *__restrict__ zbuf, uint8_t *__restrict__ out, int views,
-                                                                    int width, int height, int stride)
+                                                                    int width, int height, int stride, const uint32_t *epoch, size_t pair_words)
 {
     // requires width % 4 == 0, SIZE <= 5, stride % 4 == 0 and (SIZE == 1 or stride >= width + 4)
+    if (epoch) zbuf += (size_t)(*epoch & 1u) * pair_words;  // a level's double-buffered anchors: the buffer this replay splatted into
     const int hp = height + SIZE - 1;
     const int quads = width >> 2, strips = (height + kResolveRows - 1) / kResolveRows;
     const size_t n = (size_t)views * strips * quads;
@@ -409,24 +424,25 @@ __global__ __launch_bounds__(256) void nmi_zbuf_resolve_kernel(const uint32_t *_
     }
 }
 
-static void launch_resolve(const uint32_t *zbuf, uint8_t *out, int S, int width, int height, int size, hipStream_t stream)
+static void launch_resolve(const uint32_t *zbuf, uint8_t *out, int S, int width, int height, int size, hipStream_t stream,
+                           const uint32_t *epoch = nullptr, size_t pair_words = 0)
 {
     const int stride = zbuf_stride(width, size);
     const size_t nq = (size_t)S * height * ((width + 3) / 4);
     dim3 grid((unsigned)((nq + 255) / 256 < 8192 ? (nq + 255) / 256 : 8192)), block(256);
     const bool fast = (width & 3) == 0 && size <= 5 && (((uintptr_t)zbuf & 15) == 0) && (((uintptr_t)out & 3) == 0);
-    if (!fast) {
+    if (!fast) {  // (never with an epoch: launch_level_front_points checks resolve_fast_eligible first)
         hipLaunchKernelGGL(nmi_zbuf_resolve_kernel, grid, block, 0, stream, zbuf, out, S, width, height, size, stride);
         return;
     }
     const size_t nstrips = (size_t)S * ((height + kResolveRows - 1) / kResolveRows) * (width / 4);  // one lane per strip
     grid = dim3((unsigned)((nstrips + 255) / 256 < 8192 ? (nstrips + 255) / 256 : 8192));
     switch (size) {
-    case 1: hipLaunchKernelGGL(nmi_zbuf_resolve_fast_kernel<1>, grid, block, 0, stream, zbuf, out, S, width, height, stride); break;
-    case 2: hipLaunchKernelGGL(nmi_zbuf_resolve_fast_kernel<2>, grid, block, 0, stream, zbuf, out, S, width, height, stride); break;
-    case 3: hipLaunchKernelGGL(nmi_zbuf_resolve_fast_kernel<3>, grid, block, 0, stream, zbuf, out, S, width, height, stride); break;
-    case 4: hipLaunchKernelGGL(nmi_zbuf_resolve_fast_kernel<4>, grid, block, 0, stream, zbuf, out, S, width, height, stride); break;
-    default: hipLaunchKernelGGL(nmi_zbuf_resolve_fast_kernel<5>, grid, block, 0, stream, zbuf, out, S, width, height, stride); break;
+    case 1: hipLaunchKernelGGL(nmi_zbuf_resolve_fast_kernel<1>, grid, block, 0, stream, zbuf, out, S, width, height, stride, epoch, pair_words); break;
+    case 2: hipLaunchKernelGGL(nmi_zbuf_resolve_fast_kernel<2>, grid, block, 0, stream, zbuf, out, S, width, height, stride, epoch, pair_words); break;
+    case 3: hipLaunchKernelGGL(nmi_zbuf_resolve_fast_kernel<3>, grid, block, 0, stream, zbuf, out, S, width, height, stride, epoch, pair_words); break;
+    case 4: hipLaunchKernelGGL(nmi_zbuf_resolve_fast_kernel<4>, grid, block, 0, stream, zbuf, out, S, width, height, stride, epoch, pair_words); break;
+    default: hipLaunchKernelGGL(nmi_zbuf_resolve_fast_kernel<5>, grid, block, 0, stream, zbuf, out, S, width, height, stride, epoch, pair_words); break;
     }
 }
 
@@ -470,13 +486,18 @@ hipError_t launch_cloud_pack(const float *xyz, const float *red, long long npoin
     return hipGetLastError();
 }
 
-// Front of a captured point-cloud level: warp stack + splat in one launch (no clear: the level's prep node did it), then
-// the resolve.  S <= 64 views.
-hipError_t launch_level_front_points(const void *packed, long long npoints, const float *mvps, int S, uint32_t *zbuf, uint8_t *out,
-                                     int width, int height, int size, const uint8_t *frame, const float *coeffs, uint8_t *warps, int Wn,
-                                     hipStream_t stream)
+// Words of ONE of a level's two anchor buffers (a multiple of 4).
+size_t level_zbuf_pair_words(int S, int width, int height, int size) { return (render_zbuf_words(S, width, height, size) + 3) & ~(size_t)3; }
+
+// Front of a captured point-cloud level: warp stack + splat (+ the clear of the other anchor buffer) in one launch, then the
+// resolve.  `zbuf` holds two buffers of level_zbuf_pair_words each, both cleared at creation; `epoch` is the device word the
+// level's prep node bumps.  S <= 64 views.
+hipError_t launch_level_front_points(const void *packed, long long npoints, const float *mvps, int S, uint32_t *zbuf, const uint32_t *epoch,
+                                     uint8_t *out, int width, int height, int size, const uint8_t *frame, const float *coeffs, uint8_t *warps,
+                                     int Wn, hipStream_t stream)
 {
     if (S > kMaxViewsPerLaunch || !warp_lds_eligible(frame, warps, width)) return hipErrorInvalidValue;
+    if (!((width & 3) == 0 && size <= 5 && (((uintptr_t)zbuf & 15) == 0) && (((uintptr_t)out & 3) == 0))) return hipErrorInvalidValue;
     size_t off = 0;
     (void)cloud_pack_bytes(npoints, &off);
     PackedCloud pc{reinterpret_cast<const float4 *>(packed), reinterpret_cast<const float4 *>(static_cast<const char *>(packed) + off)};
@@ -486,12 +507,15 @@ hipError_t launch_level_front_points(const void *packed, long long npoints, cons
     if (dbg & 1) warp_blocks = 0;
     if (dbg & 2) splat_blocks = 0, npoints = 0;
     const int stride = zbuf_stride(width, size);
-    hipLaunchKernelGGL(nmi_level_front_kernel, dim3((unsigned)(warp_blocks + splat_blocks)), dim3(256), 0, stream, pc, npoints, mvps, S, zbuf,
-                       width, height, size, stride, frame, coeffs, warps, warp_blocks);
-    launch_resolve(zbuf, out, S, width, height, size, stream);
+    const size_t pair_words = level_zbuf_pair_words(S, width, height, size);
+    const int clear_blocks = 1024;
+    hipLaunchKernelGGL(nmi_level_front_kernel, dim3((unsigned)(warp_blocks + splat_blocks + clear_blocks)), dim3(256), 0, stream, pc, npoints, mvps,
+                       S, zbuf, pair_words, epoch, width, height, size, stride, frame, coeffs, warps, warp_blocks, (int)splat_blocks, clear_blocks);
+    launch_resolve(zbuf, out, S, width, height, size, stream, epoch, pair_words);
     return hipGetLastError();
 }
 
 bool level_front_eligible(const void *frame, const void *warps, int width, int S) { return S <= kMaxViewsPerLaunch && warp_lds_eligible(frame, warps, width); }
+bool level_points_double_buffered(int width, int size) { return (width & 3) == 0 && size <= 5; }
 
 }  // namespace nmi
