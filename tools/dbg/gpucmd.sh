@@ -1,4 +1,3 @@
-mkdir -p $GRAFT_REPO_ROOT/gpurun_out/r03_ah
-timeout -k 10 400 python3 -m pytest tests/test_render.py tests/test_config5.py tests/test_level_sharded.py tests/test_warp.py -q -m gpu > gpurun_out/r03_ah/tests.log 2>&1; echo rc=$? >> gpurun_out/r03_ah/tests.log; tail -3 gpurun_out/r03_ah/tests.log
-cd /tmp && export TMPDIR=/tmp
-for q in cloud 60x40 300x200; do if [ $q = cloud ]; then A=""; else A="--map mesh --mesh-quads $q"; fi; rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r03_ah/trace_$q -- python3 $GRAFT_REPO_ROOT/bench.py --config e2e $A --keyframes 20 > $GRAFT_REPO_ROOT/gpurun_out/r03_ah/trace_$q.log 2>&1; python3 $GRAFT_REPO_ROOT/tools/e2e_timeline.py $GRAFT_REPO_ROOT/gpurun_out/r03_ah/trace_$q > $GRAFT_REPO_ROOT/gpurun_out/r03_ah/e2e_timeline_$q.txt 2>&1; cat $GRAFT_REPO_ROOT/gpurun_out/r03_ah/e2e_timeline_$q.txt; done
+mkdir -p $GRAFT_REPO_ROOT/gpurun_out/r03_ai
+timeout -k 10 400 python3 -m pytest tests/test_render.py tests/test_level_sharded.py tests/test_config5.py -q -m gpu > gpurun_out/r03_ai/tests.log 2>&1; echo rc=$? >> gpurun_out/r03_ai/tests.log; tail -3 gpurun_out/r03_ai/tests.log
+timeout -k 10 200 python3 tools/mesh_time.py > gpurun_out/r03_ai/mesh_time.txt 2>&1; cat gpurun_out/r03_ai/mesh_time.txt
