@@ -419,6 +419,44 @@ def test_gpu_mesh_equal_depth_goes_to_the_triangle_drawn_first():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_gpu_mesh_random_soup_vs_twin(seed):
+    """A soup of random triangles -- pixel-sized to screen-filling, every orientation, some crossing the near plane or the
+    frustum's sides, many overlapping at different depths -- through bins, the per-lane path and overflowing bins: the three
+    give one image, and it is the twin's (coverage, depth and draw-order decisions identical; <= 1 grey level through the LOD)."""
+    torch = pytest.importorskip("torch")
+    import orbslam2_nmi_amd as nmi
+    w, h = 160, 120
+    rng = np.random.default_rng(seed)
+    rp = params(w, h)
+    n = 140
+    depth = rng.uniform(3.0, 28.0, (n, 1))                       # near plane 5, far plane 30: some in front of the near plane
+    centre_px = rng.uniform([-0.4 * w, -0.4 * h], [1.4 * w, 1.4 * h], (n, 2))
+    size_px = np.exp(rng.uniform(np.log(0.6), np.log(0.5 * w), (n, 1)))
+    corners = centre_px[:, None, :] + size_px[:, None, :] * rng.uniform(-1, 1, (n, 3, 2))
+    z = depth[:, None, :] * rng.uniform(0.7, 1.4, (n, 3, 1))     # tilted: depth varies across a triangle
+    xyz = np.concatenate([(corners[..., :1] - rp.cx) / rp.fx * z, (corners[..., 1:] - rp.cy) / rp.fy * z, z], -1).astype(np.float32)
+    uv = rng.uniform(-1.5, 2.5, (n, 3, 2)).astype(np.float32)
+    xyz, uv = _both_windings(xyz.reshape(-1, 3), uv.reshape(-1, 2))
+    B = sy.scene(128, 64, 17 + seed)
+    rgb = np.stack([B, np.roll(B, 3, 0), np.roll(B, 7, 1)], -1).astype(np.uint8)
+    mvps = np.stack([capi.render_mvp(rp, (0, 0, 0), (0, 0, 1), (0, -1, 0), t) for t in ((0, 0, 0), (0.6, -0.4, 1.5), (-1.0, 0.3, -2.0))])
+    exp = mo.render_stack(xyz, uv, mo.mip_luma(rgb), mvps, w, h)
+    assert 0.15 < (exp != 255).mean() < 0.999         # covered and background both present
+    outs = []
+    with nmi.NmiContext(w, h) as ctx, nmi.NmiTexture(ctx, rgb) as tex:
+        dx, du = torch.from_numpy(xyz).cuda(), torch.from_numpy(uv).cuda()
+        for cap, clip_cap in ((255, 1 << 18), (255, 1 << 18), (5, 1 << 18), (0, 1 << 18), (255, 2)):
+            ctx.set_option(ctx.OPT_TILE_QUEUE, cap)
+            ctx.set_option(ctx.OPT_CLIP_QUEUE, clip_cap)
+            outs.append(ctx.render_mesh(dx, du, tex, mvps).cpu().numpy())
+    assert all((outs[0] == o).all() for o in outs[1:])
+    diff = np.abs(outs[0].astype(int) - exp.astype(int))
+    assert ((outs[0] == 255) == (exp == 255)).all()
+    assert diff.max() <= 1 and (diff != 0).mean() < 2e-3, (diff.max(), (diff != 0).mean())
+
+
+@pytest.mark.gpu
 def test_gpu_mesh_to_winner_end_to_end():
     """mesh + texture + pose -> device render stack for a 3x3x1 translation grid; the frame is the mesh seen from a
     displaced pose (other gamma + noise); the search picks the nearest cell."""
