@@ -136,14 +136,14 @@ static int level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_attr, i
         if (e == hipSuccess) ok(hipMemsetAsync(lv->d_epoch, 0, sizeof(uint32_t), ctx->stream));
         if (e == hipSuccess) ok(nmi::launch_cloud_pack(d_xyz, d_red, n_points, lv->d_packed, ctx->stream));
     }
-    ok(hipMalloc((void **)&lv->d_mvps, (size_t)S * 16 * sizeof(float)));
+    ok(hipMalloc((void **)&lv->d_mvps, ((size_t)S * 16 + nmi::kLevelMvpExtra) * sizeof(float)));
     ok(hipMalloc((void **)&lv->d_coeffs, (size_t)Wn * 9 * sizeof(float)));
     ok(hipMalloc((void **)&lv->d_order, (size_t)total * sizeof(int)));
     ok(hipMalloc((void **)&lv->d_ratings, (size_t)total * sizeof(float)));
     ok(hipMalloc((void **)&lv->d_key, sizeof(unsigned long long)));
     ok(hipMalloc((void **)&lv->d_done, sizeof(unsigned int)));
     // pinned, device-mapped, fine-grained: the prep kernel reads the parameters and the search kernel posts the winner
-    ok(hipHostMalloc((void **)&lv->h_mvps, (size_t)S * 16 * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
+    ok(hipHostMalloc((void **)&lv->h_mvps, ((size_t)S * 16 + nmi::kLevelMvpExtra) * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
     ok(hipHostMalloc((void **)&lv->h_coeffs, (size_t)Wn * 9 * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
     ok(hipHostMalloc((void **)&lv->h_key, sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
     ok(hipStreamCreateWithFlags(&lv->side, hipStreamNonBlocking));
@@ -159,7 +159,7 @@ static int level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_attr, i
     ok(hipMemcpy(lv->d_order, order, (size_t)total * sizeof(int), hipMemcpyHostToDevice));
     delete[] order;
     ok(hipMemset(lv->d_done, 0, sizeof(unsigned int)));
-    memset(lv->h_mvps, 0, (size_t)S * 16 * sizeof(float));
+    memset(lv->h_mvps, 0, ((size_t)S * 16 + nmi::kLevelMvpExtra) * sizeof(float));
     memset(lv->h_coeffs, 0, (size_t)Wn * 9 * sizeof(float));
     ok(hipDeviceSynchronize());
 
@@ -196,7 +196,7 @@ static int level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_attr, i
     hipStream_t st = ctx->stream;
     if (e == hipSuccess && ok(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal))) {
         // (mesh: nothing to clear -- the renderer leaves its work area clean)
-        ok(nmi::launch_level_prep(hd_mvps, lv->d_mvps, S * 16, hd_coeffs, lv->d_coeffs, Wn * 9, lv->d_key, lv->d_zbuf,
+        ok(nmi::launch_level_prep(hd_mvps, lv->d_mvps, S * 16 + nmi::kLevelMvpExtra, hd_coeffs, lv->d_coeffs, Wn * 9, lv->d_key, lv->d_zbuf,
                                   (tex || lv->fused_points) ? 0 : nmi::render_zbuf_words(S, p.width, p.height, lv->size), st,
                                   lv->fused_points ? lv->d_epoch : nullptr));
         // One chain of kernels when the warp blocks can ride along with the render's first kernel (the usual case: frame rows
@@ -273,6 +273,9 @@ static int level_launch(nmi_level *lv, const float *h_mvps, const double *h_forw
 {
     nmi_ctx *ctx = lv->ctx;
     memcpy(lv->h_mvps, h_mvps, (size_t)lv->S * 16 * sizeof(float));
+    nmi::level_views_bound(h_mvps, lv->S, lv->h_mvps + (size_t)lv->S * 16);  // for the front kernel's first test: all views at once
+    static const bool no_bound = getenv("NMI_LEVEL_NO_BOUND") != nullptr;      // measurement switch: six zero planes cull nothing
+    if (no_bound) memset(lv->h_mvps + (size_t)lv->S * 16, 0, nmi::kLevelMvpExtra * sizeof(float));
     for (int w = 0; w < lv->Wn; ++w) {
         const double *m = h_forward + (size_t)w * 9;
         const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);

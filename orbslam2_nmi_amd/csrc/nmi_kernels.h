@@ -172,6 +172,8 @@ hipError_t sort_records_morton(const float *a, int na, int verts, const float *b
 size_t cloud_pack_bytes(long long npoints, size_t *boxes_offset);
 hipError_t launch_cloud_pack(const float *xyz, const float *red, long long npoints, void *packed, hipStream_t stream);
 bool level_front_eligible(const void *frame, const void *warps, int width, int S);
+void level_views_bound(const float *mvps /*[S][16] column-major*/, int S, float out[24]);  // host: 6 planes around the S views' frusta
+constexpr int kLevelMvpExtra = 24;  // floats behind a level's S matrices: those planes
 bool level_points_double_buffered(int width, int size);  // the fused front kernel's form of the anchors: two buffers, cleared in turn
 size_t level_zbuf_pair_words(int S, int width, int height, int size);
 hipError_t launch_level_front_points(const void *packed, long long npoints, const float *mvps, int S, uint32_t *zbuf /* two buffers */,

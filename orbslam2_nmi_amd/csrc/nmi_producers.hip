@@ -3,6 +3,7 @@
 // renderer is in nmi_mesh.hip, the scoring kernels themselves in nmi_kernels.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <math.h>
 #include <stdlib.h>
 
 #include "nmi_kernels.h"
@@ -328,8 +329,24 @@ __global__ __launch_bounds__(256) void nmi_level_front_kernel(PackedCloud pc, lo
     const uint32_t parity = *epoch & 1u;
     const long long b = (long long)blockIdx.x - warp_blocks;
     if (b < splat_blocks) {
-        splat_wave<true>(nullptr, nullptr, pc, npoints, mvps, views, zbuf + (size_t)parity * pair_words, width, height, size, stride,
-                         (b * 256 + threadIdx.x) >> 6, (int)(threadIdx.x & 63));
+        // First one test for ALL the views: the wavefront's box against six planes that hold every view's frustum (24 floats
+        // behind the matrices, made by the host for this replay -- level_views_bound).  A map is mostly elsewhere -- 8 of 9
+        // wavefronts of the benchmark's cloud -- and those neither fetch their points nor run the per-view plane tests.
+        const long long wave = (b * 256 + threadIdx.x) >> 6;
+        if (wave * 64 < npoints) {
+            const float *pl = mvps + (size_t)views * 16;  // uniform address: scalar loads
+            const float4 lo = pc.boxes[2 * wave], hi = pc.boxes[2 * wave + 1];
+            bool out = false;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const float a = pl[4 * k], bb = pl[4 * k + 1], c = pl[4 * k + 2], d = pl[4 * k + 3];
+                // the largest value the plane function takes in the box (a comparison with a NaN operand is false: kept)
+                out = out || (a * (a >= 0.0f ? hi.x : lo.x) + bb * (bb >= 0.0f ? hi.y : lo.y)) + (c * (c >= 0.0f ? hi.z : lo.z) + d) < 0.0f;
+            }
+            if (out) return;  // wavefront-uniform
+        }
+        splat_wave<true>(nullptr, nullptr, pc, npoints, mvps, views, zbuf + (size_t)parity * pair_words, width, height, size, stride, wave,
+                         (int)(threadIdx.x & 63));
         return;
     }
     uint4 *other = reinterpret_cast<uint4 *>(zbuf + (size_t)(parity ^ 1u) * pair_words);  // (pair_words is a multiple of 4)
@@ -491,7 +508,8 @@ size_t level_zbuf_pair_words(int S, int width, int height, int size) { return (r
 
 // Front of a captured point-cloud level: warp stack + splat (+ the clear of the other anchor buffer) in one launch, then the
 // resolve.  `zbuf` holds two buffers of level_zbuf_pair_words each, both cleared at creation; `epoch` is the device word the
-// level's prep node bumps.  S <= 64 views.
+// level's prep node bumps.  `mvps` holds S matrices followed by 6 planes (a, b, c, d) with every view's frustum on their
+// non-negative side (level_views_bound; all zero switches the test off).  S <= 64 views.
 hipError_t launch_level_front_points(const void *packed, long long npoints, const float *mvps, int S, uint32_t *zbuf, const uint32_t *epoch,
                                      uint8_t *out, int width, int height, int size, const uint8_t *frame, const float *coeffs, uint8_t *warps,
                                      int Wn, hipStream_t stream)
@@ -513,6 +531,80 @@ hipError_t launch_level_front_points(const void *packed, long long npoints, cons
                        S, zbuf, pair_words, epoch, width, height, size, stride, frame, coeffs, warps, warp_blocks, (int)splat_blocks, clear_blocks);
     launch_resolve(zbuf, out, S, width, height, size, stream, epoch, pair_words);
     return hipGetLastError();
+}
+
+// Six planes (a, b, c, d; a x + b y + c z + d >= 0 inside) that hold the frusta of all S views (column-major MVP matrices): per
+// side of the clip volume the views' own planes (row 3 +- row j) are averaged to one direction and pushed out until all 8 S
+// frustum corners (the corners of clip space taken back through each inverse matrix, double precision) lie inside, plus a margin
+// far above the rounding of either side's test.  A view draws only inside the hull of its corners, hence inside all six.
+// A matrix that cannot be inverted, or a corner at infinity, gives six zero planes (nothing culled).
+void level_views_bound(const float *mvps, int S, float out[24])
+{
+    for (int k = 0; k < 24; ++k) out[k] = 0.0f;
+    if (S <= 0 || S > 64) return;
+    double corners[64 * 8][3];
+    double dir[6][3] = {};
+    for (int s = 0; s < S; ++s) {
+        double m[16], inv[16];
+        for (int k = 0; k < 16; ++k) m[k] = mvps[(size_t)s * 16 + k];
+        // cofactor inverse of a 4x4
+        inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+        inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+        inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+        inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+        inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+        inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+        inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+        inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+        inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+        inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+        inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+        inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+        inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+        inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+        inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+        inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+        const double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+        if (!(fabs(det) > 1e-300)) return;
+        for (int c = 0; c < 8; ++c) {
+            const double x = (c & 1) ? 1.0 : -1.0, y = (c & 2) ? 1.0 : -1.0, z = (c & 4) ? 1.0 : -1.0;
+            double p[4];
+            for (int r = 0; r < 4; ++r) p[r] = (inv[r] * x + inv[4 + r] * y + inv[8 + r] * z + inv[12 + r]) / det;
+            // a corner must lie in front of its own view (w_clip > 0): a matrix with the volume turned inside out is not a camera
+            if (!(p[3] == p[3]) || !(fabs(p[3]) > 1e-12)) return;
+            for (int k = 0; k < 3; ++k) {
+                const double v = p[k] / p[3];
+                if (!(v == v) || fabs(v) > 1e30) return;
+                corners[s * 8 + c][k] = v;
+            }
+            const double *q = corners[s * 8 + c];
+            const double wc = m[3] * q[0] + m[7] * q[1] + m[11] * q[2] + m[15];
+            if (!(wc > 0.0)) return;
+        }
+        for (int k = 0; k < 6; ++k) {  // plane k of this view: row 3 + row j (k even) or row 3 - row j (k odd), j = k / 2
+            const int j = k >> 1;
+            const double sg = (k & 1) ? -1.0 : 1.0;
+            const double a = m[3] + sg * m[j], b = m[7] + sg * m[4 + j], c = m[11] + sg * m[8 + j];
+            const double len = sqrt(a * a + b * b + c * c);
+            if (!(len > 1e-300)) return;
+            dir[k][0] += a / len, dir[k][1] += b / len, dir[k][2] += c / len;
+        }
+    }
+    float planes[24];
+    for (int k = 0; k < 6; ++k) {
+        const double len = sqrt(dir[k][0] * dir[k][0] + dir[k][1] * dir[k][1] + dir[k][2] * dir[k][2]);
+        if (!(len > 1e-6)) return;  // the views face every which way: no common side
+        const double n[3] = {dir[k][0] / len, dir[k][1] / len, dir[k][2] / len};
+        double least = 1e300, reach = 0.0;
+        for (int i = 0; i < S * 8; ++i) {
+            const double v = n[0] * corners[i][0] + n[1] * corners[i][1] + n[2] * corners[i][2];
+            least = v < least ? v : least;
+            reach = fmax(reach, fabs(corners[i][0]) + fabs(corners[i][1]) + fabs(corners[i][2]));
+        }
+        planes[4 * k] = (float)n[0], planes[4 * k + 1] = (float)n[1], planes[4 * k + 2] = (float)n[2];
+        planes[4 * k + 3] = (float)(-least + 1e-4 * reach + 1e-6);
+    }
+    for (int k = 0; k < 24; ++k) out[k] = planes[k];
 }
 
 bool level_front_eligible(const void *frame, const void *warps, int width, int S) { return S <= kMaxViewsPerLaunch && warp_lds_eligible(frame, warps, width); }
