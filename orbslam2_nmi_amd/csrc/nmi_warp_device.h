@@ -9,6 +9,21 @@
 namespace nmi {
 namespace {
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// 1.0f / d, correctly rounded, in 4 instructions instead of the 11 of the compiler's division: the hardware's approximation
+// (1 ulp) and one Newton step in two FMAs.  Checked against the division for EVERY float on gfx950 (tests/test_render.py,
+// test_gpu_reciprocal_exhaustive): identical for all d with exponent field in [3, 252] (warp_rcp_ok); everything else --
+// zero, denormal, huge, inf, NaN -- takes the division.
+__device__ __forceinline__ bool warp_rcp_ok(float d) { return ((__float_as_uint(d) >> 23) & 0xFFu) - 3u <= 249u; }
+__device__ __forceinline__ float warp_rcp_fast(float d)
+{
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+__device__ __forceinline__ float warp_rcp(float d) { return __builtin_expect(warp_rcp_ok(d), 1) ? warp_rcp_fast(d) : 1.0f / d; }
+
 __device__ __forceinline__ float warp_tap(const uint8_t *__restrict__ src, int w, int h, int x, int y)
 {
     return (x >= 0 && x < w && y >= 0 && y < h) ? (float)src[y * w + x] : 0.0f;  // BORDER_CONSTANT, value 0
@@ -129,46 +144,71 @@ __device__ __forceinline__ void warp_lds_block(const uint8_t *__restrict__ frame
     }
     __syncthreads();
     if (q >= quads_per_row) return;
-    const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5], c6 = c[6], c7 = c[7], c8 = c[8];
+    // The loop below is bound by vector instruction issue (a wave instruction occupies its SIMD for 4 cycles: 0.6 T wave
+    // instructions/s for the whole chip; 68 instructions per pixel made this kernel 19 us for 11 M pixels).  Hence: pixels go
+    // in pairs through the packed fp32 instructions (v_pk_mul / v_pk_add: IEEE results per element, and never fused -- this
+    // file is built with -ffp-contract=off), and 1 / den comes from warp_rcp instead of the 11-instruction division.
+    const v2f c0 = {c[0], c[0]}, c3 = {c[3], c[3]}, c6 = {c[6], c[6]};
+    const float c1 = c[1], c2 = c[2], c4 = c[4], c5 = c[5], c7 = c[7], c8 = c[8];
     const float xmax = (float)(width + 1), ymax = (float)(height + 1);
+    const v2f fxa = {(float)(q * 4), (float)(q * 4 + 1)}, fxb = {(float)(q * 4 + 2), (float)(q * 4 + 3)};
+    const v2f c0xa = c0 * fxa, c0xb = c0 * fxb, c3xa = c3 * fxa, c3xb = c3 * fxb, c6xa = c6 * fxa, c6xb = c6 * fxb;  // the same for every row
+    const uint32_t lx_max = (uint32_t)(pitch - 2), ly_max = (uint32_t)(rows - 2);
 #pragma unroll 1
     for (int rr = 0; rr < kWarpRowsPerThread; ++rr) {
         const int y = by * kBlockRows + rr * 8 + ty;
         if (y >= height) break;
         const float fy = (float)y;
+        const float c1y = c1 * fy, c4y = c4 * fy, c7y = c7 * fy;
         uint32_t packed = 0;
+        // coeff = 1 / ((c6 x + c7 y) + c8) of the four pixels: one range test (and one branch) for all of them
+        const v2f den_a = (c6xa + c7y) + c8, den_b = (c6xb + c7y) + c8;
+        v2f coeff_a, coeff_b;
+        if (__builtin_expect(warp_rcp_ok(den_a.x) && warp_rcp_ok(den_a.y) && warp_rcp_ok(den_b.x) && warp_rcp_ok(den_b.y), 1)) {
+            coeff_a = v2f{warp_rcp_fast(den_a.x), warp_rcp_fast(den_a.y)}, coeff_b = v2f{warp_rcp_fast(den_b.x), warp_rcp_fast(den_b.y)};
+        } else {
+            coeff_a = v2f{1.0f / den_a.x, 1.0f / den_a.y}, coeff_b = v2f{1.0f / den_b.x, 1.0f / den_b.y};
+        }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float fx = (float)(q * 4 + k);
-            const float coeff = 1.0f / (c6 * fx + c7 * fy + c8);
-            const float xs = coeff * (c0 * fx + c1 * fy + c2);
-            const float ys = coeff * (c3 * fx + c4 * fy + c5);
+        for (int half = 0; half < 2; ++half) {
+            // pixel pair (4q + 2 half, 4q + 2 half + 1): xs = coeff ((c0 x + c1 y) + c2), ys = coeff ((c3 x + c4 y) + c5)
+            const v2f coeff = half ? coeff_b : coeff_a;
+            const v2f xs = coeff * (((half ? c0xb : c0xa) + c1y) + c2);
+            const v2f ys = coeff * (((half ? c3xb : c3xa) + c4y) + c5);
             // nmi_warp_kernel gives 0 to pixels whose source lies outside (-2, width + 1) x (-2, height + 1).  Clamping the
             // source coordinate into that closed range does the same without a test: a clamped coordinate has both of its
             // taps (or its whole 2 x 2 window) in the zero border, and it stays inside this block's patch because the patch
             // is the corners' bounding box clipped to the very same range.
-            const float xsc = __builtin_amdgcn_fmed3f(xs, -2.0f, xmax), ysc = __builtin_amdgcn_fmed3f(ys, -2.0f, ymax);
-            const float x1f = floorf(xsc), y1f = floorf(ysc);
-            // (unsigned min: a negative offset -- impossible while the bounding-box argument holds -- also ends up inside)
-            const uint32_t lx = min((uint32_t)((int)x1f - px0), (uint32_t)(pitch - 2)), ly = min((uint32_t)((int)y1f - py0), (uint32_t)(rows - 2));
-            // The two taps of a row are bytes o, o + 1 of the patch with o of any alignment.  An unaligned 2-byte LDS read
-            // costs ~200 cycles of issue stall (measured: SQ_WAIT_INST_LDS 55 units per ds_read_u16, the whole kernel 40 us
-            // however its taps were fetched), so the 8 aligned bytes around them are read and shifted instead.
-            const uint32_t o = ly * (uint32_t)pitch + lx;
-            const uint32_t *w0 = reinterpret_cast<const uint32_t *>(patch + (o & ~3u));
-            const uint32_t *w1 = reinterpret_cast<const uint32_t *>(patch + (o & ~3u) + pitch);
-            const uint32_t top = __builtin_amdgcn_alignbyte(w0[1], w0[0], o & 3u);
-            const uint32_t bot = __builtin_amdgcn_alignbyte(w1[1], w1[0], o & 3u);
-            const float t11 = (float)(top & 0xFFu), t21 = (float)((top >> 8) & 0xFFu);
-            const float t12 = (float)(bot & 0xFFu), t22 = (float)((bot >> 8) & 0xFFu);
-            const float x2f = x1f + 1.0f, y2f = y1f + 1.0f;  // exact: small integers
-            float acc = 0.0f;
-            acc = acc + t11 * ((x2f - xsc) * (y2f - ysc));
-            acc = acc + t21 * ((xsc - x1f) * (y2f - ysc));
-            acc = acc + t12 * ((x2f - xsc) * (ysc - y1f));
-            acc = acc + t22 * ((xsc - x1f) * (ysc - y1f));
+            const v2f xsc = {__builtin_amdgcn_fmed3f(xs.x, -2.0f, xmax), __builtin_amdgcn_fmed3f(xs.y, -2.0f, xmax)};
+            const v2f ysc = {__builtin_amdgcn_fmed3f(ys.x, -2.0f, ymax), __builtin_amdgcn_fmed3f(ys.y, -2.0f, ymax)};
+            const v2f x1f = {floorf(xsc.x), floorf(xsc.y)}, y1f = {floorf(ysc.x), floorf(ysc.y)};
+            v2f t11, t21, t12, t22;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                // (unsigned min: a negative offset -- impossible while the bounding-box argument holds -- also ends up inside)
+                const uint32_t lx = min((uint32_t)((int)x1f[e] - px0), lx_max), ly = min((uint32_t)((int)y1f[e] - py0), ly_max);
+                // The two taps of a row are bytes o, o + 1 of the patch with o of any alignment.  An unaligned 2-byte LDS read
+                // costs ~200 cycles of issue stall (measured: SQ_WAIT_INST_LDS 55 units per ds_read_u16, the whole kernel 40 us
+                // however its taps were fetched), so the 8 aligned bytes around them are read and shifted instead.
+                const uint32_t o = ly * (uint32_t)pitch + lx;
+                const uint32_t *w0 = reinterpret_cast<const uint32_t *>(patch + (o & ~3u));
+                const uint32_t *w1 = reinterpret_cast<const uint32_t *>(patch + (o & ~3u) + pitch);
+                const uint32_t top = __builtin_amdgcn_alignbyte(w0[1], w0[0], o & 3u);
+                const uint32_t bot = __builtin_amdgcn_alignbyte(w1[1], w1[0], o & 3u);
+                t11[e] = (float)(top & 0xFFu), t21[e] = (float)((top >> 8) & 0xFFu);
+                t12[e] = (float)(bot & 0xFFu), t22[e] = (float)((bot >> 8) & 0xFFu);
+            }
+            const v2f x2f = x1f + 1.0f, y2f = y1f + 1.0f;  // exact: small integers
+            const v2f ax = x2f - xsc, bx = xsc - x1f, ay = y2f - ysc, bw = ysc - y1f;
+            // 0 + t11 w11 + t21 w21 + t12 w12 + t22 w22 in nmi_warp_kernel's order; its leading "0 +" changes nothing here
+            // (taps and weights are >= +0, so the first product is never -0)
+            v2f acc = t11 * (ax * ay);
+            acc = acc + t21 * (bx * ay);
+            acc = acc + t12 * (ax * bw);
+            acc = acc + t22 * (bx * bw);
             // saturate_cast<uchar>: round to nearest even, clamp; acc >= 0, and the pack instruction saturates at 255
-            packed = __builtin_amdgcn_cvt_pk_u8_f32(rintf(acc), k, packed);
+            packed = __builtin_amdgcn_cvt_pk_u8_f32(rintf(acc.x), 2 * half, packed);
+            packed = __builtin_amdgcn_cvt_pk_u8_f32(rintf(acc.y), 2 * half + 1, packed);
         }
         *reinterpret_cast<uint32_t *>(out + ((size_t)wi * height + y) * width + q * 4) = packed;
     }

@@ -561,3 +561,20 @@ def test_gpu_sorted_maps_are_permutations_and_render_identically():
         e = torch.empty((0, 3), dtype=torch.float32, device="cuda")
         ex, er = ctx.sort_points(e, torch.empty(0, dtype=torch.float32, device="cuda"))
         assert ex.shape[0] == 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The short reciprocal of the producers (nmi_warp_device.h: hardware approximation + one Newton step instead of the
+# compiler's 11-instruction division) must have the division's bits: checked for every float on the GPU at hand.
+
+@pytest.mark.gpu
+def test_gpu_reciprocal_exhaustive():
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "examples", "rcp_check")
+    if not os.access(exe, os.X_OK):  # normally prebuilt by __graft_entry__.build(); hipcc exists on the GPU box too
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "rcp_check"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "RCP OK" in r.stdout, r.stdout + r.stderr

@@ -1,7 +1,7 @@
-O=$GRAFT_REPO_ROOT/gpurun_out/r03_al; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/r03_ao; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-for v in a b a2 b2; do
-  case $v in a*) unset NMI_LEVEL_NO_BOUND;; b*) export NMI_LEVEL_NO_BOUND=1;; esac
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/$v -- $GRAFT_REPO_ROOT/examples/level_pipeline 100 > $O/$v.log 2>&1
-  echo "== $v"; grep -h "front\|resolve" $(find $O/$v -name "*kernel_stats.csv") | cut -d, -f1-4
+for d in 5 13 21 37; do
+  export NMI_FRONT_DBG=$d
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/d$d -- $GRAFT_REPO_ROOT/examples/level_pipeline 40 > $O/d$d.log 2>&1
+  echo "dbg=$d $(grep -h front_kernel $(find $O/d$d -name '*kernel_stats.csv') | awk -F, '{print $(NF-6), $(NF-5), $(NF-4)}')"
 done
