@@ -8,6 +8,7 @@
 
 #include "nmi_kernels.h"
 #include "nmi_warp_device.h"
+#include "nmi_cloud_device.h"
 
 namespace nmi {
 
@@ -193,44 +194,12 @@ __device__ __forceinline__ T wave_max(T v)
 __device__ __forceinline__ void splat_point(const float *__restrict__ m, float x, float y, float z, uint32_t colour, uint32_t *__restrict__ zbuf,
                                             int s, int width, int height, int size, int stride)
 {
-    // glm mat4 * vec4: (m0*x + m1*y) + (m2*z + m3*1), component-wise
-    const float cx = (m[0] * x + m[4] * y) + (m[8] * z + m[12]);
-    const float cy = (m[1] * x + m[5] * y) + (m[9] * z + m[13]);
-    const float cz = (m[2] * x + m[6] * y) + (m[10] * z + m[14]);
-    const float cw = (m[3] * x + m[7] * y) + (m[11] * z + m[15]);
-    if (!(cw > 0.0f) || cx < -cw || cx > cw || cy < -cw || cy > cw || cz < -cw || cz > cw) return;  // point clipping
-    // the perspective divide as one (correctly rounded) reciprocal and three products: a third of the three divisions' cost
-    const float iw = 1.0f / cw;
-    const float xw = (cx * iw * 0.5f + 0.5f) * (float)width;
-    const float yw = (cy * iw * 0.5f + 0.5f) * (float)height;
-    const float zw = cz * iw * 0.5f + 0.5f;
-    const uint32_t depth = (uint32_t)(zw * 16777215.0f + 0.5f);
-    const uint32_t frag = (depth << 8) | colour;
-    int x0, y0;
-    if (size & 1) {
-        x0 = (int)floorf(xw) - (size - 1) / 2;
-        y0 = (int)floorf(yw) - (size - 1) / 2;
-    } else {
-        x0 = (int)floorf(xw + 0.5f) - size / 2;
-        y0 = (int)floorf(yw + 0.5f) - size / 2;
-    }
-    // Only the sprite's anchor (its lowest-left pixel) is written here: one atomic per point and view instead of
-    // size^2.  Two points with the same anchor have the same footprint, so the farther one would lose on every
-    // pixel anyway; the resolve pass below takes, for each pixel, the minimum over the size^2 anchors whose
-    // sprites cover it -- exactly the depth-tested sprites.  The buffer is padded by size-1 so that sprites
-    // straddling the left / bottom edge keep their anchor.
-    const int ax = x0 + size - 1, ay = y0 + size - 1, wp = width + size - 1, hp = height + size - 1;
-    if (ax < 0 || ax >= wp || ay < 0 || ay >= hp) return;
+    int ax, ay;
+    uint32_t frag;
+    if (!splat_anchor(m, x, y, z, colour, width, height, size, ax, ay, frag)) return;
+    const int hp = height + size - 1;
     atomicMin(&zbuf[((size_t)s * hp + ay) * stride + ax], frag);
 }
-
-// The cloud as a level keeps it (nmi_level_create): one 16-byte record per point -- x, y, z, red -- so that a lane fetches its
-// point with ONE load instead of four 4-byte loads 12 bytes apart, and the bounding box of every wavefront's 64 points,
-// computed once (the cloud of a level does not change), instead of 36 cross-lane reductions per wavefront and launch.
-struct PackedCloud {
-    const float4 *points;  // [n]
-    const float4 *boxes;   // [2 * ceil(n / 64)]: lo.xyz, hi.xyz of each wavefront's points
-};
 
 __global__ __launch_bounds__(256) void nmi_cloud_pack_kernel(const float *__restrict__ xyz, const float *__restrict__ red, long long npoints,
                                                              float4 *__restrict__ points, float4 *__restrict__ boxes)
@@ -280,30 +249,8 @@ __device__ __forceinline__ void splat_wave(const float *__restrict__ xyz, const 
         hix = wave_max(valid ? x : -inf), hiy = wave_max(valid ? y : -inf), hiz = wave_max(valid ? z : -inf);
     }
 
-    // ---- which views can these points reach? ----
-    const float ax = fmaxf(fabsf(lox), fabsf(hix)), ay = fmaxf(fabsf(loy), fabsf(hiy)), az = fmaxf(fabsf(loz), fabsf(hiz));
-    bool outside = lane >= views;
-    {
-        const float row[4][4] = {{c0.x, c1.x, c2.x, c3.x}, {c0.y, c1.y, c2.y, c3.y}, {c0.z, c1.z, c2.z, c3.z}, {c0.w, c1.w, c2.w, c3.w}};
-        // magnitude of the terms of cw anywhere in the box (rounding of a 4-term fp32 sum is below 3e-7 of it; margin 1e-5)
-        const float mw = fabsf(row[3][0]) * ax + fabsf(row[3][1]) * ay + fabsf(row[3][2]) * az + fabsf(row[3][3]);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const float e = 1e-5f * (fabsf(row[j][0]) * ax + fabsf(row[j][1]) * ay + fabsf(row[j][2]) * az + fabsf(row[j][3]) + mw);
-#pragma unroll
-            for (int sgn = 0; sgn < 2; ++sgn) {
-                // plane  cw + c_j >= 0  (sgn 0: c_j >= -cw)   or   cw - c_j >= 0  (sgn 1: c_j <= cw)
-                const float a = sgn ? row[3][0] - row[j][0] : row[3][0] + row[j][0];
-                const float b = sgn ? row[3][1] - row[j][1] : row[3][1] + row[j][1];
-                const float c = sgn ? row[3][2] - row[j][2] : row[3][2] + row[j][2];
-                const float d = sgn ? row[3][3] - row[j][3] : row[3][3] + row[j][3];
-                // the largest value the plane function takes in the box (comparisons with NaN / inf operands are false)
-                const float best = (a * (a >= 0.0f ? hix : lox) + b * (b >= 0.0f ? hiy : loy)) + (c * (c >= 0.0f ? hiz : loz) + d);
-                // the coefficients themselves carry one rounding each: covered by the same margin (twice)
-                outside = outside || best < -2.0f * e;
-            }
-        }
-    }
+    // ---- which views can these points reach? ----  (lane v tests view v: nmi_cloud_device.h)
+    const bool outside = lane >= views || box_outside_view(c0, c1, c2, c3, lox, loy, loz, hix, hiy, hiz);
     unsigned long long todo = ~__ballot(outside);
     if (views < 64) todo &= (1ull << views) - 1ull;
     const uint32_t colour = (uint32_t)(fminf(fmaxf(r, 0.0f), 1.0f) * 255.0f + 0.5f);
@@ -349,15 +296,8 @@ __global__ __launch_bounds__(256) void nmi_level_front_kernel(PackedCloud pc, lo
         // wavefronts of the benchmark's cloud -- and those neither fetch their points nor run the per-view plane tests.
         const long long wave = (b * 256 + threadIdx.x) >> 6;
         if (wave * 64 < npoints) {
-            const float *pl = mvps + (size_t)views * 16;  // uniform address: scalar loads
             const float4 lo = pc.boxes[2 * wave], hi = pc.boxes[2 * wave + 1];
-            bool out = false;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const float a = pl[4 * k], bb = pl[4 * k + 1], c = pl[4 * k + 2], d = pl[4 * k + 3];
-                // the largest value the plane function takes in the box (a comparison with a NaN operand is false: kept)
-                out = out || (a * (a >= 0.0f ? hi.x : lo.x) + bb * (bb >= 0.0f ? hi.y : lo.y)) + (c * (c >= 0.0f ? hi.z : lo.z) + d) < 0.0f;
-            }
+            const bool out = box_outside_bound(mvps + (size_t)views * 16, lo, hi);
             if (out) return;  // wavefront-uniform
         }
         splat_wave<true>(nullptr, nullptr, pc, npoints, mvps, views, zbuf + (size_t)parity * pair_words, width, height, size, stride, wave,
