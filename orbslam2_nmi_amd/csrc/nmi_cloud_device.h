@@ -1,10 +1,11 @@
-// nmi_cloud_device.h -- device code shared by the two point-cloud renderers: the scatter form (nmi_producers.hip: one global
-// atomicMin per point and view, then a resolve pass) and the tiled form of a captured level (nmi_cloud_tiles.hip: wavefronts
-// binned to 64 x 64 tiles, depth test in LDS, resolve fused).  Both evaluate a point with splat_anchor below, so they agree
-// bit for bit by construction.
+// nmi_cloud_device.h -- per-point and per-box device arithmetic of the point-cloud renderer (nmi_producers.hip: one global
+// atomicMin per point and view, then a resolve pass), kept apart from the kernels so that every kernel that splats or culls
+// evaluates a point with the same expressions.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "nmi_warp_device.h"
 
 namespace nmi {
 
@@ -23,33 +24,38 @@ namespace {
 // Only the anchor is written by either renderer: two points with the same anchor have the same footprint, so the farther
 // one would lose on every pixel anyway; a pixel's value is the minimum over the size^2 anchors whose sprites cover it.
 // Returns false for a clipped point or an anchor outside the padded buffer.
+// The view loops are bound by vector-instruction issue, so this is written for instruction count: components in pairs through
+// the packed fp32 instructions ((cx, cy) and (cz, cw) -- the matrix is column-major, so each pair's coefficients are adjacent
+// floats; IEEE results per element, never fused: -ffp-contract=off), the six clip comparisons as one maximum of magnitudes, and
+// the reciprocal by warp_rcp (nmi_warp_device.h: bit-identical to the division, checked for every float).  Values are those of
+// the plain expressions in the comments, bit for bit (the fp32 twin oracle/render_oracle_np.py checks them).
 template <typename M>
 __device__ __forceinline__ bool splat_anchor(const M &m, float x, float y, float z, uint32_t colour, int width, int height, int size, int &ax,
                                              int &ay, uint32_t &frag)
 {
-    // glm mat4 * vec4: (m0*x + m1*y) + (m2*z + m3*1), component-wise
-    const float cx = (m[0] * x + m[4] * y) + (m[8] * z + m[12]);
-    const float cy = (m[1] * x + m[5] * y) + (m[9] * z + m[13]);
-    const float cz = (m[2] * x + m[6] * y) + (m[10] * z + m[14]);
-    const float cw = (m[3] * x + m[7] * y) + (m[11] * z + m[15]);
-    if (!(cw > 0.0f) || cx < -cw || cx > cw || cy < -cw || cy > cw || cz < -cw || cz > cw) return false;  // point clipping
-    // the perspective divide as one (correctly rounded) reciprocal and three products: a third of the three divisions' cost
-    const float iw = 1.0f / cw;
-    const float xw = (cx * iw * 0.5f + 0.5f) * (float)width;
-    const float yw = (cy * iw * 0.5f + 0.5f) * (float)height;
-    const float zw = cz * iw * 0.5f + 0.5f;
+    // glm mat4 * vec4: c_r = (m[r]*x + m[4+r]*y) + (m[8+r]*z + m[12+r])
+    const v2f X = {x, x}, Y = {y, y}, Z = {z, z};
+    const v2f cxy = (v2f{m[0], m[1]} * X + v2f{m[4], m[5]} * Y) + (v2f{m[8], m[9]} * Z + v2f{m[12], m[13]});
+    const v2f czw = (v2f{m[2], m[3]} * X + v2f{m[6], m[7]} * Y) + (v2f{m[10], m[11]} * Z + v2f{m[14], m[15]});
+    const float cw = czw.y;
+    // point clipping:  !(cw > 0) || cx < -cw || cx > cw || cy < -cw || cy > cw || cz < -cw || cz > cw.  The six comparisons are
+    // "the largest magnitude exceeds cw" (fmaxf passes over a NaN operand, and a comparison with NaN is false, exactly as there)
+    if (!(cw > 0.0f)) return false;
+    if (fmaxf(fmaxf(fabsf(cxy.x), fabsf(cxy.y)), fabsf(czw.x)) > cw) return false;
+    // the perspective divide as one (correctly rounded) reciprocal and three products:
+    //   xw = (cx * iw * 0.5f + 0.5f) * width, yw likewise with height, zw = cz * iw * 0.5f + 0.5f
+    const float iw = warp_rcp(cw);
+    const v2f win = ((cxy * iw) * 0.5f + 0.5f) * v2f{(float)width, (float)height};
+    const float zw = czw.x * iw * 0.5f + 0.5f;
     const uint32_t depth = (uint32_t)(zw * 16777215.0f + 0.5f);
     frag = (depth << 8) | colour;
-    int x0, y0;
-    if (size & 1) {
-        x0 = (int)floorf(xw) - (size - 1) / 2;
-        y0 = (int)floorf(yw) - (size - 1) / 2;
-    } else {
-        x0 = (int)floorf(xw + 0.5f) - size / 2;
-        y0 = (int)floorf(yw + 0.5f) - size / 2;
-    }
-    ax = x0 + size - 1, ay = y0 + size - 1;
-    return ax >= 0 && ax < width + size - 1 && ay >= 0 && ay < height + size - 1;
+    // odd sizes are centred on floor(xw) + 0.5, even sizes on floor(xw + 0.5); the anchor is the sprite's lowest-left pixel in the
+    // buffer padded by size - 1:  x0 + size - 1
+    const float r = (size & 1) ? 0.0f : 0.5f;
+    const int back = (size & 1) ? (size - 1) / 2 : size / 2;
+    ax = (int)floorf(win.x + r) - back + size - 1;   // (win.x + 0.0f has win.x's bits unless win.x is -0: floor gives -0 -> 0 either way)
+    ay = (int)floorf(win.y + r) - back + size - 1;
+    return (uint32_t)ax < (uint32_t)(width + size - 1) && (uint32_t)ay < (uint32_t)(height + size - 1);
 }
 
 // Can the box [lo, hi] reach the view whose matrix has the columns c0..c3?  For each of the six clip planes the box corner

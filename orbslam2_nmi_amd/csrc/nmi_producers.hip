@@ -197,8 +197,8 @@ __device__ __forceinline__ void splat_point(const float *__restrict__ m, float x
     int ax, ay;
     uint32_t frag;
     if (!splat_anchor(m, x, y, z, colour, width, height, size, ax, ay, frag)) return;
-    const int hp = height + size - 1;
-    atomicMin(&zbuf[((size_t)s * hp + ay) * stride + ax], frag);
+    uint32_t *zview = zbuf + (size_t)s * (height + size - 1) * stride;   // wavefront-uniform in the callers' view loops: scalar arithmetic
+    atomicMin(&zview[ay * stride + ax], frag);
 }
 
 __global__ __launch_bounds__(256) void nmi_cloud_pack_kernel(const float *__restrict__ xyz, const float *__restrict__ red, long long npoints,
