@@ -196,7 +196,8 @@ int nmi_render_points(nmi_ctx *ctx, const float *d_xyz, const float *d_red, int6
  *   nmi_texture_create  takes the RGB8 image exactly as loadBMP_custom passes it to glTexImage2D (texture.cpp:31-86: row 0
  *                       = v 0, three bytes per texel in file order; the shader weighs byte 0 with 0.299, byte 1 with 0.587,
  *                       byte 2 with 0.114), builds the mip chain glGenerateMipmap would (2x2 box, RGB8 per level) and keeps
- *                       per-level luma on the device.
+ *                       per-level luma on the device.  Sides up to 32,768 texels and at most 2^30 texels in the whole
+ *                       pyramid (a 28,000 x 28,000 image), else NMI_ERR_UNSUPPORTED.
  *   nmi_render_mesh     d_xyz float [3*T][3] and d_uv float [3*T][2]: the expanded per-corner arrays loadOBJ produces
  *                       (objloader.cpp:140-224); h_mvps as for nmi_render_points; output uint8 [S][H][W], bottom-up rows,
  *                       background 255.  Back faces culled (counter-clockwise front), depth test LESS, GL_REPEAT,

@@ -227,6 +227,10 @@ int nmi_texture_create(nmi_ctx *ctx, const uint8_t *h_rgb, int32_t tw, int32_t t
         lw = lw > 1 ? lw / 2 : 1;
         lh = lh > 1 ? lh / 2 : 1;
     }
+    if (total >= (1ll << 30)) {  // the sampler addresses the pyramid with 32-bit byte offsets (4 bytes per texel)
+        delete tex;
+        return NMI_ERR_UNSUPPORTED;
+    }
     std::vector<uint8_t> cur(h_rgb, h_rgb + (size_t)tw * th * 3), next;
     std::vector<float> luma((size_t)total);
     for (int l = 0; l < tex->levels; ++l) {

@@ -87,17 +87,32 @@ __device__ __forceinline__ void tex_level_fill(const MeshTexture &t, int l, TexL
     *out = L;
 }
 
-__device__ __forceinline__ float tex_bilinear(const float *__restrict__ luma, const TexLevel &L, float u, float v)
+// GL_LINEAR sample of one level at (u, v) with GL_REPEAT.  Written for instruction count (the shading loop is bound by
+// instruction issue): the common texel -- both taps of both rows inside the level -- takes its indices by plain conversion and its
+// taps as two 8-byte loads at 32-bit offsets from the pyramid's base; only a sample on the level's border wraps (wrap_index) and
+// fetches four single taps.  Values are those of the plain expressions:
+//   x = u w - 0.5, y = v h - 0.5;  i0 = floor(x) mod w, i1 = (i0 + 1) mod w, rows likewise;  a = t00 + (t10 - t00) fx, b = t01 + (t11 - t01) fx;  a + (b - a) fy
+__device__ __forceinline__ float tex_bilinear(const float *__restrict__ luma, const TexLevel &L, v2f uv)
 {
-    const float x = u * L.w - 0.5f, y = v * L.h - 0.5f;
-    const float xf = floorf(x), yf = floorf(y);
-    const float fx = x - xf, fy = y - yf;
-    const uint32_t i0 = (uint32_t)wrap_index(xf, L.w, L.inv_w), j0 = (uint32_t)wrap_index(yf, L.h, L.inv_h);  // GL_REPEAT
-    const uint32_t i1 = i0 + 1 == L.wi ? 0 : i0 + 1, j1 = j0 + 1 == L.hi ? 0 : j0 + 1;
-    const float *p = luma + (((unsigned long long)L.off_hi << 32) | L.off_lo);
-    const float t00 = p[(size_t)j0 * L.wi + i0], t10 = p[(size_t)j0 * L.wi + i1], t01 = p[(size_t)j1 * L.wi + i0], t11 = p[(size_t)j1 * L.wi + i1];
-    const float a = t00 + (t10 - t00) * fx, b = t01 + (t11 - t01) * fx;
-    return a + (b - a) * fy;
+    const v2f xy = uv * v2f{L.w, L.h} - 0.5f;
+    const v2f fl = {floorf(xy.x), floorf(xy.y)};
+    const v2f fr = xy - fl;
+    const int xi = (int)fl.x, yi = (int)fl.y;
+    const char *base = reinterpret_cast<const char *>(luma);   // (a pyramid is far below 4 GB: 32-bit byte offsets, scalar base)
+    float t00, t10, t01, t11;   // (plain scalars: vectors assigned on two paths end up in a promoted stack slot, i.e. in LDS)
+    if (__builtin_expect((uint32_t)xi < L.wi - 1u && (uint32_t)yi < L.hi - 1u, 1)) {
+        const uint32_t o = (L.off_lo + (uint32_t)yi * L.wi + (uint32_t)xi) * 4u;
+        const float2 top = *reinterpret_cast<const float2 *>(base + o), bot = *reinterpret_cast<const float2 *>(base + (o + L.wi * 4u));
+        t00 = top.x, t10 = top.y, t01 = bot.x, t11 = bot.y;
+    } else {
+        const uint32_t i0 = (uint32_t)wrap_index(fl.x, L.w, L.inv_w), j0 = (uint32_t)wrap_index(fl.y, L.h, L.inv_h);  // GL_REPEAT
+        const uint32_t i1 = i0 + 1 == L.wi ? 0 : i0 + 1, j1 = j0 + 1 == L.hi ? 0 : j0 + 1;
+        const uint32_t r0 = L.off_lo + j0 * L.wi, r1 = L.off_lo + j1 * L.wi;
+        t00 = *reinterpret_cast<const float *>(base + (r0 + i0) * 4u), t10 = *reinterpret_cast<const float *>(base + (r0 + i1) * 4u);
+        t01 = *reinterpret_cast<const float *>(base + (r1 + i0) * 4u), t11 = *reinterpret_cast<const float *>(base + (r1 + i1) * 4u);
+    }
+    const v2f ab = v2f{t00, t01} + (v2f{t10, t11} - v2f{t00, t01}) * fr.x;
+    return ab.x + (ab.y - ab.x) * fr.y;
 }
 
 __device__ __forceinline__ bool edge_owner(float ex, float ey)
@@ -274,9 +289,10 @@ __device__ __forceinline__ bool tri_cover(const TriView &t, float fxp, float fyp
 // Gx (x - xr) + Gy (y - yr) about the centre (xr, yr) of the first pixel of the triangle's box.  The barycentric weights are
 // affine in the pixel position, so the planes carry the same interpolation as weights evaluated per pixel, at 6 operations
 // per attribute instead of 18 + 9; u = S / Q, v = R / Q.
-struct Planes {
+struct Planes {   // S = u/w and R = v/w as pairs (the shader runs them through the packed fp32 instructions), Q = 1/w
     float xr, yr;
-    float s0, sx, sy, r0, rx, ry, q0, qx, qy;
+    v2f sr0, srx, sry;   // (s0, r0), (sx, rx), (sy, ry)
+    float q0, qx, qy;
 };
 
 __device__ __forceinline__ void tri_planes(const TriView &t, const float (&tu)[3], const float (&tv)[3], Planes &P)
@@ -293,12 +309,9 @@ __device__ __forceinline__ void tri_planes(const TriView &t, const float (&tu)[3
         s[k] = tu[k] * t.iw[k];
         r[k] = tv[k] * t.iw[k];
     }
-    P.s0 = (b[0] * s[0] + b[1] * s[1]) + b[2] * s[2];
-    P.sx = (bx[0] * s[0] + bx[1] * s[1]) + bx[2] * s[2];
-    P.sy = (by[0] * s[0] + by[1] * s[1]) + by[2] * s[2];
-    P.r0 = (b[0] * r[0] + b[1] * r[1]) + b[2] * r[2];
-    P.rx = (bx[0] * r[0] + bx[1] * r[1]) + bx[2] * r[2];
-    P.ry = (by[0] * r[0] + by[1] * r[1]) + by[2] * r[2];
+    P.sr0 = v2f{(b[0] * s[0] + b[1] * s[1]) + b[2] * s[2], (b[0] * r[0] + b[1] * r[1]) + b[2] * r[2]};
+    P.srx = v2f{(bx[0] * s[0] + bx[1] * s[1]) + bx[2] * s[2], (bx[0] * r[0] + bx[1] * r[1]) + bx[2] * r[2]};
+    P.sry = v2f{(by[0] * s[0] + by[1] * s[1]) + by[2] * s[2], (by[0] * r[0] + by[1] * r[1]) + by[2] * r[2]};
     P.q0 = (b[0] * t.iw[0] + b[1] * t.iw[1]) + b[2] * t.iw[2];
     P.qx = (bx[0] * t.iw[0] + bx[1] * t.iw[1]) + bx[2] * t.iw[2];
     P.qy = (by[0] * t.iw[0] + by[1] * t.iw[1]) + by[2] * t.iw[2];
@@ -309,18 +322,24 @@ __device__ __forceinline__ void tri_planes(const TriView &t, const float (&tu)[3
 __device__ __forceinline__ uint32_t shade_pixel(const Planes &P, const float *__restrict__ luma_base, const TexLevel *levels, int n_levels,
                                             float fxp, float fyp)
 {
+    // S = (s0 + sx dx) + sy dy, R and Q likewise; u = S / Q at the pixel, at its right neighbour (S + sx, Q + qx) and at its upper one.
+    // S and R go as a pair through the packed fp32 instructions; the three reciprocals are warp_rcp's (the division's bits).
     const float dx = fxp - P.xr, dy = fyp - P.yr;
-    const float S = (P.s0 + P.sx * dx) + P.sy * dy;
-    const float R = (P.r0 + P.rx * dx) + P.ry * dy;
+    const v2f SR = (P.sr0 + P.srx * dx) + P.sry * dy;
     const float Q = (P.q0 + P.qx * dx) + P.qy * dy;
-    const float iq = 1.0f / Q, iqx = 1.0f / (Q + P.qx), iqy = 1.0f / (Q + P.qy);
-    const float u = S * iq, v = R * iq;
-    const float ux = (S + P.sx) * iqx, vx = (R + P.rx) * iqx;
-    const float uy = (S + P.sy) * iqy, vy = (R + P.ry) * iqy;
-    const float tw = levels[0].w, th = levels[0].h;
-    const float dudx = (ux - u) * tw, dvdx = (vx - v) * th, dudy = (uy - u) * tw, dvdy = (vy - v) * th;
+    const float Qx = Q + P.qx, Qy = Q + P.qy;
+    float iq, iqx, iqy;
+    if (__builtin_expect(warp_rcp_ok(Q) && warp_rcp_ok(Qx) && warp_rcp_ok(Qy), 1))
+        iq = warp_rcp_fast(Q), iqx = warp_rcp_fast(Qx), iqy = warp_rcp_fast(Qy);
+    else
+        iq = 1.0f / Q, iqx = 1.0f / Qx, iqy = 1.0f / Qy;
+    const v2f uv = SR * iq;
+    const v2f uvx = (SR + P.srx) * iqx, uvy = (SR + P.sry) * iqy;
+    const v2f twh = {levels[0].w, levels[0].h};
+    const v2f ddx = (uvx - uv) * twh, ddy = (uvy - uv) * twh;   // (du/dx tw, dv/dx th), (du/dy tw, dv/dy th)
     // lambda = log2(rho), rho = the longer of the two footprint axes: log2 of a square root is half the log2 of the square
-    const float rho2 = fmaxf(dudx * dudx + dvdx * dvdx, dudy * dudy + dvdy * dvdy);
+    const v2f sqx = ddx * ddx, sqy = ddy * ddy;
+    const float rho2 = fmaxf(sqx.x + sqx.y, sqy.x + sqy.y);
     const float lambda = 0.5f * log2f(rho2);
     // magnification (lambda <= 0, or NaN): GL_LINEAR on the base level; minification: GL_LINEAR_MIPMAP_LINEAR between levels
     // floor(lambda) and the next.  One code path: with lambda clamped to 0 the lower level is the base level, and the upper
@@ -328,9 +347,9 @@ __device__ __forceinline__ uint32_t shade_pixel(const Planes &P, const float *__
     const float lc = fminf(fmaxf(lambda, 0.0f), (float)(n_levels - 1));
     const int l0 = (int)floorf(lc), l1 = min(l0 + 1, n_levels - 1);
     const float f = lc - (float)l0;
-    float luma = tex_bilinear(luma_base, levels[l0], u, v);
+    float luma = tex_bilinear(luma_base, levels[l0], uv);
     if (lambda > 0.0f) {
-        const float s1 = tex_bilinear(luma_base, levels[l1], u, v);
+        const float s1 = tex_bilinear(luma_base, levels[l1], uv);
         luma = luma + (s1 - luma) * f;
     }
     return (uint32_t)(fminf(fmaxf(luma, 0.0f), 1.0f) * 255.0f + 0.5f);
@@ -612,7 +631,7 @@ enum : int {
     R_BOX_W = 12,   // the box's width | its pixels << 16
     R_FIRST = 13,   // box pixels of the records before this one
     R_ID = 14,      // triangle << 1 | piece
-    R_PLANES = 16,  // xr, yr, s0, sx, sy, r0, rx, ry, q0, qx, qy
+    R_PLANES = 16,  // xr, yr, s0, r0, sx, rx, sy, ry, q0, qx, qy
     R_WORDS = 28,
 };
 
@@ -631,7 +650,7 @@ __device__ __forceinline__ int key_index(int x, int y) { return y * kTile + ((x 
 __device__ __forceinline__ void planes_from_lds(const uint32_t *r, Planes &P)
 {
     const float *f = reinterpret_cast<const float *>(r + R_PLANES);
-    P.xr = f[0], P.yr = f[1], P.s0 = f[2], P.sx = f[3], P.sy = f[4], P.r0 = f[5], P.rx = f[6], P.ry = f[7], P.q0 = f[8], P.qx = f[9], P.qy = f[10];
+    P.xr = f[0], P.yr = f[1], P.sr0 = v2f{f[2], f[3]}, P.srx = v2f{f[4], f[5]}, P.sry = v2f{f[6], f[7]}, P.q0 = f[8], P.qx = f[9], P.qy = f[10];
 }
 
 }  // namespace
@@ -697,8 +716,8 @@ __global__ __launch_bounds__(kTileThreads) void nmi_mesh_tile_kernel(const float
 #pragma unroll
                 for (int k = 0; k < 3; ++k) f[R_XW + k] = t.xw[k], f[R_YW + k] = t.yw[k], f[R_ZW + k] = t.zw[k];
                 f[R_INV_AREA] = t.inv_area;
-                f[R_PLANES + 0] = P.xr, f[R_PLANES + 1] = P.yr, f[R_PLANES + 2] = P.s0, f[R_PLANES + 3] = P.sx, f[R_PLANES + 4] = P.sy;
-                f[R_PLANES + 5] = P.r0, f[R_PLANES + 6] = P.rx, f[R_PLANES + 7] = P.ry, f[R_PLANES + 8] = P.q0, f[R_PLANES + 9] = P.qx;
+                f[R_PLANES + 0] = P.xr, f[R_PLANES + 1] = P.yr, f[R_PLANES + 2] = P.sr0.x, f[R_PLANES + 3] = P.sr0.y, f[R_PLANES + 4] = P.srx.x;
+                f[R_PLANES + 5] = P.srx.y, f[R_PLANES + 6] = P.sry.x, f[R_PLANES + 7] = P.sry.y, f[R_PLANES + 8] = P.q0, f[R_PLANES + 9] = P.qx;
                 f[R_PLANES + 10] = P.qy;
                 r[R_OWN] = (t.own[0] ? 1u : 0u) | (t.own[1] ? 2u : 0u) | (t.own[2] ? 4u : 0u);
                 r[R_BOX] = (uint32_t)bx0 | ((uint32_t)by0 << 16);

@@ -1,14 +1,11 @@
-O=$GRAFT_REPO_ROOT/gpurun_out/r03_aq; mkdir -p $O
-timeout -k 10 400 python3 -m pytest tests/test_render.py tests/test_config5.py tests/test_level_sharded.py -q -m gpu -x > $O/tests.log 2>&1; echo rc=$? >> $O/tests.log; tail -15 $O/tests.log
+O=$GRAFT_REPO_ROOT/gpurun_out/r03_au; mkdir -p $O
+timeout -k 10 500 python3 -m pytest tests/test_render.py -q -m gpu -x > $O/tests.log 2>&1; echo rc=$? >> $O/tests.log; tail -3 $O/tests.log
 cd /tmp && export TMPDIR=/tmp
-for d in 0 5; do
-  export NMI_FRONT_DBG=$d
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/d$d -- $GRAFT_REPO_ROOT/examples/level_pipeline 100 > $O/d$d.log 2>&1
-  echo "== dbg $d"; python3 - $O/d$d <<'PY'
-import csv,sys,glob
-f=glob.glob(f'{sys.argv[1]}/**/*kernel_stats.csv',recursive=True)[0]
-for r in list(csv.DictReader(open(f)))[:6]:
-    print(r['Name'][:40], r['Calls'], r['AverageNs'])
-PY
-  tail -2 $O/d$d.log
-done
+for v in old new; do
+for m in "60 40" "300 200"; do
+for d in 0 1; do
+  export NMI_MESH_DBG=$d NMI_HIP_LIBRARY=$GRAFT_REPO_ROOT/build/ab/$v.so
+  tag=${v}_$(echo $m | tr ' ' x)_d$d
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$tag -- python3 $GRAFT_REPO_ROOT/tools/mesh_profile.py $m 20 > $O/$tag.log 2>&1
+  echo "$v mesh $m dbg=$d $(grep -h 'mesh_tile_kernel' $(find $O/$tag -name '*kernel_stats.csv') | awk -F, '{printf "%s %.1f  ", substr($1,7,18), $(NF-4)/1000}')"
+done; done; done
