@@ -645,6 +645,8 @@ struct TileLds {
 
 // Where the key of tile pixel (x, y) lives: row y, rotated by 8 keys per row (a multiple of 4: a lane's four neighbouring
 // output pixels stay neighbours).
+constexpr int kVisChunk = 8;  // steps (pixel pairs) of one record a lane takes at a time in the visibility walk
+
 __device__ __forceinline__ int key_index(int x, int y) { return y * kTile + ((x + 8 * y) & (kTile - 1)); }
 
 __device__ __forceinline__ void planes_from_lds(const uint32_t *r, Planes &P)
@@ -721,8 +723,9 @@ __global__ __launch_bounds__(kTileThreads) void nmi_mesh_tile_kernel(const float
                 f[R_PLANES + 10] = P.qy;
                 r[R_OWN] = (t.own[0] ? 1u : 0u) | (t.own[1] ? 2u : 0u) | (t.own[2] ? 4u : 0u);
                 r[R_BOX] = (uint32_t)bx0 | ((uint32_t)by0 << 16);
-                nst = (uint32_t)((bx1 - bx0 + 1) * (by1 - by0 + 1));  // at most 4096
-                r[R_BOX_W] = (uint32_t)(bx1 - bx0 + 1) | (nst << 16);
+                const uint32_t nsteps = (uint32_t)(((bx1 - bx0 + 2) >> 1) * (by1 - by0 + 1));  // steps of the visibility walk: pairs of pixels in a row; at most 2048
+                nst = (nsteps + kVisChunk - 1) / kVisChunk;                                      // ... taken in chunks of kVisChunk
+                r[R_BOX_W] = (uint32_t)(bx1 - bx0 + 1) | (nsteps << 16);
             } else {
                 r[R_BOX_W] = 0u;
             }
@@ -747,82 +750,86 @@ __global__ __launch_bounds__(kTileThreads) void nmi_mesh_tile_kernel(const float
         if (tid < n) lds.rec[tid][R_FIRST] = before + incl - nst;
         __syncthreads();
         // ---- visibility -------------------------------------------------------------------------------------------------------
-        // The pixel boxes of all records, one after the other, form one long list of (record, pixel) pairs; every lane takes an
-        // equal, contiguous share of it and walks it alone: its record's corners in its own registers (reloaded when the share
-        // runs into the next record), coverage + depth per pixel, ds_min_u64 on the pixel's key.  All 512 lanes have a pixel in
-        // every step whatever the triangles' sizes -- 64-pixel stamps laid over each box, a wavefront per record, had 20-40 %
-        // of their lanes inside the box for the 9 x 9-pixel boxes of a 120 k-triangle mesh and ran 3 steps per record.
-        const uint32_t per = (total + kTileThreads - 1) / kTileThreads;
-        uint32_t p = (uint32_t)tid * per;
-        const uint32_t pend = min(total, p + per);
-        if (p < pend && !(g.dbg & 6)) {
-            int lo = 0, hi = n - 1;  // the last record that starts at or before p (records without pixels share their successor's start)
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (lds.rec[mid][R_FIRST] <= p)
-                    lo = mid;
-                else
-                    hi = mid - 1;
-            }
-            int i = lo - 1;
-            TriView t;
-            uint32_t own = 0, left = 0;       // pixels of the current record still to visit (0: load the next record first)
-            int xx = 0, yy = 0, x_first = 0, x_last = 0;
-            unsigned long long key_lo = 0;
-            while (p < pend) {
-                if (left == 0) {
-                    ++i;
-                    const uint32_t *r = lds.rec[i];
-                    const uint32_t bw_n = r[R_BOX_W], first = r[R_FIRST], npx = bw_n >> 16;
-                    if (p >= first + npx) continue;  // (a record without pixels)
-                    const float *f = reinterpret_cast<const float *>(r);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) t.xw[k] = f[R_XW + k], t.yw[k] = f[R_YW + k], t.zw[k] = f[R_ZW + k];
-                    t.inv_area = f[R_INV_AREA];
-                    own = r[R_OWN];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const int a = (k + 1) % 3, b = (k + 2) % 3;
-                        t.ex[k] = t.xw[b] - t.xw[a];
-                        t.ey[k] = t.yw[b] - t.yw[a];
-                    }
-                    const uint32_t bw = bw_n & 0xFFFFu, local = p - first;
-                    const uint32_t row = local / bw;
-                    x_first = (int)(r[R_BOX] & 0xFFFFu);
-                    x_last = x_first + (int)bw - 1;
-                    xx = x_first + (int)(local - row * bw);
-                    yy = (int)(r[R_BOX] >> 16) + (int)row;
-                    left = min(npx - local, pend - p);
-                    key_lo = ((unsigned long long)r[R_ID] << 9) | (unsigned long long)(uint32_t)i;
+        // A step is two horizontally adjacent pixels of a record's box; a record's steps are cut into chunks of kVisChunk, and the
+        // chunks of all records form one list that the 512 lanes deal out among themselves.  Every lane of a wavefront is then at
+        // the same point of the same code at all times -- find the chunk's record, load its corners, take kVisChunk steps -- whatever
+        // the triangles' sizes: no lane waits while another reloads.  (Lanes walking equal contiguous shares of the PIXEL list,
+        // each reloading its record wherever its share ran into the next one, spent the walk in divergent reload passes: 45 us
+        // of a 112 us kernel, and halving the arithmetic of a step changed nothing.  64-pixel stamps laid over each box, a
+        // wavefront per record, had 20-40 % of their lanes inside the box for the 9 x 9-pixel boxes of a 120 k-triangle mesh.)
+        // Coverage + depth of both pixels of a step go through the packed fp32 instructions; ds_min_u64 on each covered pixel's key.
+        if (!(g.dbg & 6)) {
+            for (uint32_t c = (uint32_t)tid; c < total; c += kTileThreads) {
+                int lo = 0, hi = n - 1;  // the last record that starts at or before chunk c (records without pixels share their successor's start)
+                while (lo < hi && !(g.dbg & 64)) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (lds.rec[mid][R_FIRST] <= c)
+                        lo = mid;
+                    else
+                        hi = mid - 1;
                 }
-                // coverage (top-left rule) and depth of pixel (xx, yy): tri_cover with per-lane ownership bits
-                const float fxp = (float)xx + 0.5f, fyp = (float)yy + 0.5f;
-                float bary[3];
-                uint32_t in = 1u;
+                const int i = (g.dbg & 64) ? (int)(c % (uint32_t)n) : lo;
+                const uint32_t *r = lds.rec[i];
+                const float *f = reinterpret_cast<const float *>(r);
+                TriView t;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) t.xw[k] = f[R_XW + k], t.yw[k] = f[R_YW + k], t.zw[k] = f[R_ZW + k];
+                t.inv_area = f[R_INV_AREA];
+                const uint32_t own = r[R_OWN];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const int a = (k + 1) % 3;
-                    bary[k] = (t.ex[k] * (fyp - t.yw[a]) - t.ey[k] * (fxp - t.xw[a])) * t.inv_area;
-                    in &= (uint32_t)(bary[k] > 0.0f) | ((uint32_t)(bary[k] == 0.0f) & (own >> k));
+                    const int a = (k + 1) % 3, b = (k + 2) % 3;
+                    t.ex[k] = t.xw[b] - t.xw[a];
+                    t.ey[k] = t.yw[b] - t.yw[a];
                 }
-                const float z = (bary[0] * t.zw[0] + bary[1] * t.zw[1]) + bary[2] * t.zw[2];
-                if ((in & (uint32_t)(z >= 0.0f) & (uint32_t)(z <= 1.0f)) != 0u && !(g.dbg & 16)) {
-                    const uint32_t depth = min((uint32_t)(z * 16777215.0f + 0.5f), 0xFFFFFFu);
-                    (void)__hip_atomic_fetch_min(&lds.keys[key_index(xx - X0, yy - Y0)], ((unsigned long long)depth << 40) | key_lo, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t bw_n = r[R_BOX_W], nsteps = bw_n >> 16, bw = bw_n & 0xFFFFu, per_row = (bw + 1u) >> 1;
+                uint32_t step = (c - r[R_FIRST]) * kVisChunk;
+                const uint32_t row0 = step / per_row;
+                const int x_first = (int)(r[R_BOX] & 0xFFFFu), x_last = x_first + (int)bw - 1;
+                int xx = x_first + 2 * (int)(step - row0 * per_row), yy = (int)(r[R_BOX] >> 16) + (int)row0;
+                const unsigned long long key_lo = ((unsigned long long)r[R_ID] << 9) | (unsigned long long)(uint32_t)i;
+#pragma unroll
+                for (int st = 0; st < ((g.dbg & 32) ? 0 : kVisChunk); ++st, ++step) {
+                    // coverage (top-left rule) and depth of the pixels (xx, yy) and (xx + 1, yy): tri_cover with per-lane ownership bits
+                    const v2f fxp = {(float)xx + 0.5f, (float)xx + 1.5f};   // ((float)(xx + 1) + 0.5f: small integers, exact either way)
+                    const float fyp = (float)yy + 0.5f;
+                    v2f bary[3];
+                    bool in0 = step < nsteps, in1 = in0 & (xx < x_last);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int a = (k + 1) % 3;
+                        const float ea = t.ex[k] * (fyp - t.yw[a]);
+                        bary[k] = (v2f{ea, ea} - (fxp - t.xw[a]) * t.ey[k]) * t.inv_area;
+                        const bool owns = ((own >> k) & 1u) != 0u;
+                        // (bitwise on purpose: the short-circuit forms compile to a maze of 30 branches per step)
+                        in0 = in0 & ((bary[k].x > 0.0f) | ((bary[k].x == 0.0f) & owns));
+                        in1 = in1 & ((bary[k].y > 0.0f) | ((bary[k].y == 0.0f) & owns));
+                    }
+                    const v2f z = (bary[0] * t.zw[0] + bary[1] * t.zw[1]) + bary[2] * t.zw[2];
+                    if (!(g.dbg & 16)) {
+                        const v2f zq = z * 16777215.0f + 0.5f;
+                        if (in0 & (z.x >= 0.0f) & (z.x <= 1.0f)) {
+                            const uint32_t depth = min((uint32_t)zq.x, 0xFFFFFFu);
+                            (void)__hip_atomic_fetch_min(&lds.keys[key_index(xx - X0, yy - Y0)], ((unsigned long long)depth << 40) | key_lo,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        if (in1 & (z.y >= 0.0f) & (z.y <= 1.0f)) {
+                            const uint32_t depth = min((uint32_t)zq.y, 0xFFFFFFu);
+                            (void)__hip_atomic_fetch_min(&lds.keys[key_index(xx + 1 - X0, yy - Y0)], ((unsigned long long)depth << 40) | key_lo,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                    if (xx + 2 > x_last)
+                        xx = x_first, ++yy;
+                    else
+                        xx += 2;
                 }
-                ++p;
-                --left;
-                if (xx == x_last)
-                    xx = x_first, ++yy;
-                else
-                    ++xx;
             }
         }
         __syncthreads();
     }
     if (!col_ok) return;
-#pragma unroll 1
+#pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int y = oy + 32 * half;
         if (y >= height) break;

@@ -1,4 +1,4 @@
-O=$GRAFT_REPO_ROOT/gpurun_out/r03_au; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/r03_aw; mkdir -p $O
 timeout -k 10 500 python3 -m pytest tests/test_render.py -q -m gpu -x > $O/tests.log 2>&1; echo rc=$? >> $O/tests.log; tail -3 $O/tests.log
 cd /tmp && export TMPDIR=/tmp
 for v in old new; do
