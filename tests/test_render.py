@@ -182,6 +182,42 @@ def test_gpu_level_graph_equals_separate_calls():
                 assert got == ctx.search_grid(rs, ws), lvl
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_gpu_level_cull_by_common_planes_changes_nothing(seed):
+    """A level's front kernel first tests a wavefront's box against six planes around ALL the views' frusta (made by the host per
+    replay, level_views_bound).  Views that look in different directions from different places, a cloud that fills a volume far
+    larger than any frustum (most wavefronts are culled, many straddle a frustum's side): the level's renders must be exactly
+    nmi_render_points' (which has no such test)."""
+    torch = pytest.importorskip("torch")
+    import orbslam2_nmi_amd as nmi
+    w, h, S, Wn = 160, 120, 9, 2
+    rng = np.random.default_rng(seed)
+    K = sy.intrinsics(w, h)
+    rp = capi.RenderParams(fx=K[0, 0], fy=K[1, 1], cx=K[0, 2], cy=K[1, 2], near_plane=0.5, far_plane=40.0, point_size=3.0)
+    n = 200_000
+    xyz = (rng.uniform(-1, 1, (n, 3)) * [12, 9, 12] + [0, 0, 8]).astype(np.float32)
+    xyz = xyz[np.lexsort((xyz[:, 0], xyz[:, 1], xyz[:, 2]))]   # wavefronts = compact runs, as a sorted map has them
+    red = rng.uniform(0, 1, n).astype(np.float32)
+    mvps = []
+    for _ in range(S):
+        pos = rng.uniform(-1.5, 1.5, 3)
+        look = pos + np.array([rng.uniform(-0.6, 0.6), rng.uniform(-0.4, 0.4), 1.0])
+        mvps.append(capi.render_mvp(rp, pos, look, (0, -1, 0), rng.uniform(-0.3, 0.3, 3)))
+    mvps = np.stack(mvps)
+    Ms = capi.warp_homographies(K, (Wn, 1, 1), (0.02, 0.02, 0.05))
+    with nmi.NmiContext(w, h) as ctx:
+        dx, dr = torch.from_numpy(xyz).cuda(), torch.from_numpy(red).cuda()
+        frame = ctx.render_points(dx, dr, mvps[:1], 3.0)[0].contiguous()
+        want = ctx.render_points(dx, dr, mvps, 3.0).cpu().numpy()
+        assert 0.2 < float((want != 255).mean()) < 1.0   # the views see the cloud, and not only the cloud
+        with nmi.NmiLevel(ctx, dx, dr, frame, S, Wn, 3.0) as lv:
+            for rep in range(2):   # (the double-buffered anchors: both parities)
+                lv.run(mvps, Ms)
+                renders = lv.outputs()[0]
+                assert np.array_equal(renders, want), (seed, rep, int((renders != want).sum()))
+
+
 # ---- textured-mesh mode (nmi_prop_RENDER 1) --------------------------------------------------------------------------
 from oracle import mesh_oracle_np as mo  # noqa: E402
 
