@@ -368,7 +368,8 @@ struct BinGrid {
     unsigned long long *zbuf;  // [views][height][width] keys of the direct path, all ones between renders
     int stride, cap;       // entries per bin allocated / usable (cap <= stride, cap <= 511; 0: everything goes the direct way)
     int tiles_x, tiles_y;
-    int dbg;               // profiling ablations (NMI_MESH_DBG, tools only): bit 0 no shading, 1 no visibility sweep, 2 no set-up, 3 no tile work at all
+    int dbg;               // profiling ablations (NMI_MESH_DBG, tools only): bit 0 no shading, 1 no visibility sweep, 2 no set-up, 3 no tile work at all,
+                           // 4 no key updates, 5 no visibility steps, 6 no record search; bin kernel: 7 stop after the frustum test, 8 no appends
 };
 
 // The direct path: coverage + depth of the triangle's pixels inside [x0, x1] x [y0, y1], visibility by a 64-bit atomicMin in
@@ -445,30 +446,42 @@ struct ClipItem {
     uint32_t view, pad;
 };
 
-// Appends `id` to bin `want`; the lanes of a wavefront that want the same bin share one counter update, and the updates of
-// the different bins of a call are ONE atomic instruction (their latencies overlap: a wavefront of neighbouring triangles
-// touches ~8 bins per view, and 8 dependent device atomics per view was most of this kernel's time).  `want` < 0: this lane
-// has nothing to append (it still takes part).  Returns the slot, or -1 when the bin is full.
-__device__ __forceinline__ int bin_append(const BinGrid &g, int want, uint32_t id)
+// Appending `id` to bin `want`, in two halves so that a caller with several appends pays one memory round trip for all of them:
+// bin_reserve groups the lanes of the wavefront by bin -- the lanes that want the same bin share one counter update, and the
+// updates of the different bins of a call are ONE atomic instruction -- and ISSUES that update; bin_commit, called after all the
+// reservations of a batch, reads the answer and stores the entry.  (A device atomic that returns takes ~2 us here; a wavefront of
+// neighbouring triangles touches several bins per view and two to four tiles each: one round trip per tile step and view was most
+// of the bin kernel's time.)  `want` < 0: this lane has nothing to append (it still takes part in both halves).
+struct BinTicket {
+    int leader;       // lowest lane of this lane's group
+    uint32_t rank;    // this lane's position in the group
+    uint32_t base;    // the counter before the group's update (valid in the leader, once the atomic has returned)
+};
+
+__device__ __forceinline__ BinTicket bin_reserve(const BinGrid &g, int want)
 {
     const int lane = (int)(threadIdx.x & 63);
     const unsigned long long below = (1ull << lane) - 1ull;
-    // group the lanes by bin: leader = lowest lane of the group, rank = position in it, size = lanes in it
-    int leader = lane;
-    uint32_t rank = 0, size = 1;
+    BinTicket t{lane, 0u, 0u};
+    uint32_t size = 1;
     unsigned long long todo = __ballot(want >= 0);
     while (todo) {  // wavefront-uniform, one round per distinct bin, no memory access
         const int first = __builtin_ctzll(todo);
         const int b = __shfl(want, first, 64);
         const unsigned long long same = __ballot(want == b);
-        if (want == b) leader = first, rank = (uint32_t)__popcll(same & below), size = (uint32_t)__popcll(same);
+        if (want == b) t.leader = first, t.rank = (uint32_t)__popcll(same & below), size = (uint32_t)__popcll(same);
         todo &= ~same;
     }
-    uint32_t base = 0;
-    if (want >= 0 && lane == leader) base = atomicAdd(&g.state[2 * (size_t)want], size);
-    base = (uint32_t)__shfl((int)base, leader, 64);
+    if (want >= 0 && lane == t.leader) t.base = atomicAdd(&g.state[2 * (size_t)want], size);
+    return t;
+}
+
+// Returns the slot, or -1 when the bin is full (or want < 0).
+__device__ __forceinline__ int bin_commit(const BinGrid &g, int want, uint32_t id, const BinTicket &t)
+{
+    const uint32_t base = (uint32_t)__shfl((int)t.base, t.leader, 64);
     if (want < 0) return -1;
-    const uint32_t at = base + rank;
+    const uint32_t at = base + t.rank;
     if (at >= (uint32_t)g.cap) return -1;
     g.bins[(size_t)want * g.stride + at] = id;
     return (int)at;
@@ -509,6 +522,8 @@ __global__ __launch_bounds__(256) void nmi_mesh_bin_kernel(const float *__restri
     const bool valid = tri < ntri;
     float px[3] = {0, 0, 0}, py[3] = {0, 0, 0}, pz[3] = {0, 0, 0}, tu[3], tv[3];
     if (valid) load_tri(xyz, uv, tri, px, py, pz, tu, tv);
+    // (Fetching the block's corners through LDS with 16-byte loads instead -- a lane's nine floats lie 36 bytes from its
+    // neighbour's -- measured slower: 12.8 vs 10.4 us for this kernel up to the frustum test, 120 k triangles.)
     {
         // a triangle all of whose corners are beyond one clip plane is rejected by tri_setup; the block's box decides
         // that for its 256 triangles at once
@@ -520,6 +535,7 @@ __global__ __launch_bounds__(256) void nmi_mesh_bin_kernel(const float *__restri
         block_frustum_cull(m_all, v_first, v_end, lo, hi, wave_box, beyond);
     }
     const int tiles = g.tiles_x * g.tiles_y;
+    if (g.dbg & 128) return;
     for (int s = v_first; s < v_end; ++s) {
         if (beyond[s]) continue;  // block-uniform
         TriView t;
@@ -530,27 +546,39 @@ __global__ __launch_bounds__(256) void nmi_mesh_bin_kernel(const float *__restri
             if (n_in == 3) {
                 if (tri_setup(cx, cy, cz, cw, width, height, t)) {
                     const int bw = t.x_hi - t.x_lo + 1, bh = t.y_hi - t.y_lo + 1;
-                    large = bw * bh > kSmallBox && g.cap > 0;
-                    if (!large) raster_direct(t, t.x_lo, t.x_hi, t.y_lo, t.y_hi, (unsigned long long)tri << 1, g, s, width, height);
+                    large = bw * bh > kSmallBox && g.cap > 0 && !(g.dbg & 256);
+                    if (!large && !(g.dbg & 256)) raster_direct(t, t.x_lo, t.x_hi, t.y_lo, t.y_hi, (unsigned long long)tri << 1, g, s, width, height);
                 }
             } else if (n_in > 0) {  // crosses the near plane: nmi_mesh_clip_kernel's business
                 const unsigned long long at = atomicAdd(&clip_state[0], 1ull);
                 if (at < clip_cap) clipq[at] = ClipItem{(unsigned long long)tri, (uint32_t)s, 0u};
             }
         }
-        // large triangles: one bin entry per tile their box touches.  All lanes of the wavefront walk their tiles together.
+        // large triangles: one bin entry per tile their box touches.  All lanes of the wavefront walk their tiles together, four
+        // tile steps to a batch: the batch's counter updates are in flight together (bin_reserve), then its entries are stored.
         const int tx0 = large ? t.x_lo / kTile : 0, tx1 = large ? t.x_hi / kTile : -1, ty0 = large ? t.y_lo / kTile : 0, ty1 = large ? t.y_hi / kTile : -1;
         int cxt = tx0, cyt = ty0;
         bool more = large;
         while (__any(more)) {
-            const int b = s * tiles + cyt * g.tiles_x + cxt;
-            const int slot = bin_append(g, more ? b : -1, (uint32_t)(tri << 1));
-            if (more && slot < 0)  // bin full: this lane rasterises its triangle's part of the tile itself
-                raster_direct(t, max(t.x_lo, cxt * kTile), min(t.x_hi, cxt * kTile + kTile - 1), max(t.y_lo, cyt * kTile),
-                              min(t.y_hi, cyt * kTile + kTile - 1), (unsigned long long)tri << 1, g, s, width, height);
-            if (more && ++cxt > tx1) {
-                cxt = tx0;
-                if (++cyt > ty1) more = false;
+            constexpr int kBatch = 4;
+            int want[kBatch], at_x[kBatch], at_y[kBatch];
+            BinTicket ticket[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                want[u] = more ? s * tiles + cyt * g.tiles_x + cxt : -1;
+                at_x[u] = cxt, at_y[u] = cyt;
+                ticket[u] = bin_reserve(g, want[u]);
+                if (more && ++cxt > tx1) {
+                    cxt = tx0;
+                    if (++cyt > ty1) more = false;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                const int slot = bin_commit(g, want[u], (uint32_t)(tri << 1), ticket[u]);
+                if (want[u] >= 0 && slot < 0)  // bin full: this lane rasterises its triangle's part of the tile itself
+                    raster_direct(t, max(t.x_lo, at_x[u] * kTile), min(t.x_hi, at_x[u] * kTile + kTile - 1), max(t.y_lo, at_y[u] * kTile),
+                                  min(t.y_hi, at_y[u] * kTile + kTile - 1), (unsigned long long)tri << 1, g, s, width, height);
             }
         }
     }
