@@ -55,7 +55,7 @@ __device__ __forceinline__ bool splat_anchor(const M &m, float x, float y, float
     const int back = (size & 1) ? (size - 1) / 2 : size / 2;
     ax = (int)floorf(win.x + r) - back + size - 1;   // (win.x + 0.0f has win.x's bits unless win.x is -0: floor gives -0 -> 0 either way)
     ay = (int)floorf(win.y + r) - back + size - 1;
-    return (uint32_t)ax < (uint32_t)(width + size - 1) && (uint32_t)ay < (uint32_t)(height + size - 1);
+    return ((uint32_t)ax < (uint32_t)(width + size - 1)) & ((uint32_t)ay < (uint32_t)(height + size - 1));
 }
 
 // Can the box [lo, hi] reach the view whose matrix has the columns c0..c3?  For each of the six clip planes the box corner
@@ -83,7 +83,7 @@ __device__ __forceinline__ bool box_outside_view(float4 c0, float4 c1, float4 c2
             // the largest value the plane function takes in the box (comparisons with NaN / inf operands are false)
             const float best = (a * (a >= 0.0f ? hix : lox) + b * (b >= 0.0f ? hiy : loy)) + (c * (c >= 0.0f ? hiz : loz) + d);
             // the coefficients themselves carry one rounding each: covered by the same margin (twice)
-            outside = outside || best < -2.0f * e;
+            outside = outside | (best < -2.0f * e);   // (bitwise: no branch per plane)
         }
     }
     return outside;
@@ -98,7 +98,7 @@ __device__ __forceinline__ bool box_outside_bound(const float *__restrict__ pl, 
     for (int k = 0; k < 6; ++k) {
         const float a = pl[4 * k], b = pl[4 * k + 1], c = pl[4 * k + 2], d = pl[4 * k + 3];
         // the largest value the plane function takes in the box (a comparison with a NaN operand is false: kept)
-        out = out || (a * (a >= 0.0f ? hi.x : lo.x) + b * (b >= 0.0f ? hi.y : lo.y)) + (c * (c >= 0.0f ? hi.z : lo.z) + d) < 0.0f;
+        out = out | ((a * (a >= 0.0f ? hi.x : lo.x) + b * (b >= 0.0f ? hi.y : lo.y)) + (c * (c >= 0.0f ? hi.z : lo.z) + d) < 0.0f);
     }
     return out;
 }

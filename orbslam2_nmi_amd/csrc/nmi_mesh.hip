@@ -100,7 +100,7 @@ __device__ __forceinline__ float tex_bilinear(const float *__restrict__ luma, co
     const int xi = (int)fl.x, yi = (int)fl.y;
     const char *base = reinterpret_cast<const char *>(luma);   // (a pyramid is far below 4 GB: 32-bit byte offsets, scalar base)
     float t00, t10, t01, t11;   // (plain scalars: vectors assigned on two paths end up in a promoted stack slot, i.e. in LDS)
-    if (__builtin_expect((uint32_t)xi < L.wi - 1u && (uint32_t)yi < L.hi - 1u, 1)) {
+    if (__builtin_expect(((uint32_t)xi < L.wi - 1u) & ((uint32_t)yi < L.hi - 1u), 1)) {
         const uint32_t o = (L.off_lo + (uint32_t)yi * L.wi + (uint32_t)xi) * 4u;
         const float2 top = *reinterpret_cast<const float2 *>(base + o), bot = *reinterpret_cast<const float2 *>(base + (o + L.wi * 4u));
         t00 = top.x, t10 = top.y, t01 = bot.x, t11 = bot.y;
@@ -119,7 +119,7 @@ __device__ __forceinline__ bool edge_owner(float ex, float ey)
 {
     // top-left rule for a counter-clockwise triangle in y-up window coordinates: an edge owns the pixels exactly on it
     // when it is a left edge (going down) or a top edge (horizontal, going left)
-    return ey < 0.0f || (ey == 0.0f && ex < 0.0f);
+    return (ey < 0.0f) | ((ey == 0.0f) & (ex < 0.0f));
 }
 
 // One triangle seen by one view: what coverage and depth need.
@@ -203,10 +203,11 @@ __device__ __forceinline__ void poly_corners(const ClipPoly &P, int sub, float (
 __device__ __forceinline__ bool tri_setup(const float (&cx)[3], const float (&cy)[3], const float (&cz)[3], const float (&cw)[3], int width,
                                           int height, TriView &t)
 {
-    if (!(cw[0] > 0.0f) || !(cw[1] > 0.0f) || !(cw[2] > 0.0f)) return false;  // (a corner on or behind the eye plane survives near clipping only with a degenerate matrix)
-    if ((cx[0] < -cw[0] && cx[1] < -cw[1] && cx[2] < -cw[2]) || (cx[0] > cw[0] && cx[1] > cw[1] && cx[2] > cw[2]) ||
-        (cy[0] < -cw[0] && cy[1] < -cw[1] && cy[2] < -cw[2]) || (cy[0] > cw[0] && cy[1] > cw[1] && cy[2] > cw[2]) ||
-        (cz[0] < -cw[0] && cz[1] < -cw[1] && cz[2] < -cw[2]) || (cz[0] > cw[0] && cz[1] > cw[1] && cz[2] > cw[2]))
+    // (bitwise & and | on purpose, here and below: the short-circuit forms compile to one branch per comparison)
+    if (!((cw[0] > 0.0f) & (cw[1] > 0.0f) & (cw[2] > 0.0f))) return false;  // (a corner on or behind the eye plane survives near clipping only with a degenerate matrix)
+    if (((cx[0] < -cw[0]) & (cx[1] < -cw[1]) & (cx[2] < -cw[2])) | ((cx[0] > cw[0]) & (cx[1] > cw[1]) & (cx[2] > cw[2])) |
+        ((cy[0] < -cw[0]) & (cy[1] < -cw[1]) & (cy[2] < -cw[2])) | ((cy[0] > cw[0]) & (cy[1] > cw[1]) & (cy[2] > cw[2])) |
+        ((cz[0] < -cw[0]) & (cz[1] < -cw[1]) & (cz[2] < -cw[2])) | ((cz[0] > cw[0]) & (cz[1] > cw[1]) & (cz[2] > cw[2])))
         return false;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -221,7 +222,7 @@ __device__ __forceinline__ bool tri_setup(const float (&cx)[3], const float (&cy
     const float miny = fminf(t.yw[0], fminf(t.yw[1], t.yw[2])), maxy = fmaxf(t.yw[0], fmaxf(t.yw[1], t.yw[2]));
     t.x_lo = max(0, (int)ceilf(minx - 0.5f)), t.x_hi = min(width - 1, (int)floorf(maxx - 0.5f));
     t.y_lo = max(0, (int)ceilf(miny - 0.5f)), t.y_hi = min(height - 1, (int)floorf(maxy - 0.5f));
-    if (t.x_lo > t.x_hi || t.y_lo > t.y_hi) return false;
+    if ((t.x_lo > t.x_hi) | (t.y_lo > t.y_hi)) return false;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int a = (k + 1) % 3, b = (k + 2) % 3;
@@ -329,7 +330,7 @@ __device__ __forceinline__ uint32_t shade_pixel(const Planes &P, const float *__
     const float Q = (P.q0 + P.qx * dx) + P.qy * dy;
     const float Qx = Q + P.qx, Qy = Q + P.qy;
     float iq, iqx, iqy;
-    if (__builtin_expect(warp_rcp_ok(Q) && warp_rcp_ok(Qx) && warp_rcp_ok(Qy), 1))
+    if (__builtin_expect(warp_rcp_ok(Q) & warp_rcp_ok(Qx) & warp_rcp_ok(Qy), 1))
         iq = warp_rcp_fast(Q), iqx = warp_rcp_fast(Qx), iqy = warp_rcp_fast(Qy);
     else
         iq = 1.0f / Q, iqx = 1.0f / Qx, iqy = 1.0f / Qy;
@@ -907,7 +908,7 @@ __global__ __launch_bounds__(kTileThreads) void nmi_mesh_tile_kernel(const float
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const unsigned long long key = keys[k];
-            if (key != kEmptyKey && ox + k < width && !(g.dbg & 1)) {
+            if ((key != kEmptyKey) & (ox + k < width) & !(g.dbg & 1)) {
                 Planes P;
                 planes_from_lds(lds.rec[(uint32_t)(key & 0x1FFu)], P);
                 const uint32_t grey = shade_pixel(P, tex.luma, lds.tex, tex.levels, (float)(ox + k) + 0.5f, (float)y + 0.5f);

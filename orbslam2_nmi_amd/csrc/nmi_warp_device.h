@@ -164,7 +164,7 @@ __device__ __forceinline__ void warp_lds_block(const uint8_t *__restrict__ frame
         // coeff = 1 / ((c6 x + c7 y) + c8) of the four pixels: one range test (and one branch) for all of them
         const v2f den_a = (c6xa + c7y) + c8, den_b = (c6xb + c7y) + c8;
         v2f coeff_a, coeff_b;
-        if (__builtin_expect(warp_rcp_ok(den_a.x) && warp_rcp_ok(den_a.y) && warp_rcp_ok(den_b.x) && warp_rcp_ok(den_b.y), 1)) {
+        if (__builtin_expect(warp_rcp_ok(den_a.x) & warp_rcp_ok(den_a.y) & warp_rcp_ok(den_b.x) & warp_rcp_ok(den_b.y), 1)) {
             coeff_a = v2f{warp_rcp_fast(den_a.x), warp_rcp_fast(den_a.y)}, coeff_b = v2f{warp_rcp_fast(den_b.x), warp_rcp_fast(den_b.y)};
         } else {
             coeff_a = v2f{1.0f / den_a.x, 1.0f / den_a.y}, coeff_b = v2f{1.0f / den_b.x, 1.0f / den_b.y};
