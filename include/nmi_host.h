@@ -121,6 +121,26 @@ typedef struct nmi_config {
 int nmi_config_parse(const char *text, size_t len, nmi_config *out);
 int nmi_config_load(const char *yaml_path, nmi_config *out);
 
+/*
+ * Map files (the paths of nmi_config.render_object / render_texture / render_cloud / render_offset), read with the grammar and
+ * the tolerances of the reference's loaders, into the host arrays the render producers of nmi_hip.h take after an upload
+ * (and, once, nmi_sort_triangles / nmi_sort_points):
+ *   nmi_map_load_obj  loadOBJ, objloader.cpp:140-224: "v", "vt", "f a/b c/d e/f" lines -> one vertex per face corner:
+ *                     xyz float [n_vertices][3], uv float [n_vertices][2] (n_vertices = 3 * triangles) -- nmi_render_mesh
+ *   nmi_map_load_xyz  loadXYZ, objloader.cpp:226-264: "x y z r g b" per point, minus the three numbers of the offset file
+ *                     (in double precision), colour * 1/256 -> xyz float [n][3], red float [n] -- nmi_render_points;
+ *                     rgb (may be NULL) float [n][3], the whole scaled colour
+ *   nmi_map_load_bmp  loadBMP_custom, texture.cpp:31-86: 24-bit uncompressed BMP -> uint8 [height][width][3] in file order
+ *                     (row 0 = v 0) -- nmi_texture_create
+ * Buffers are malloc'ed; release each with nmi_map_free.  Returns 0, or <0: -1 argument, -2 not in the format (an OBJ face
+ * that is not three position/texcoord pairs, a point with fewer than six numbers, a BMP that is not 24-bit uncompressed or is
+ * shorter than its header says), -3 OBJ index outside the file's lists, -5 file not readable, -6 out of memory.
+ */
+int nmi_map_load_obj(const char *path, float **xyz, float **uv, int64_t *n_vertices);
+int nmi_map_load_xyz(const char *path, const char *offset_path, float **xyz, float **red, float **rgb, int64_t *n_points);
+int nmi_map_load_bmp(const char *path, uint8_t **rgb, int32_t *width, int32_t *height);
+void nmi_map_free(void *p);
+
 #ifdef __cplusplus
 }
 #endif

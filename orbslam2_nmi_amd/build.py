@@ -50,7 +50,7 @@ ABLATE_LIB = os.path.join(LIB_DIR, "libnmi_hip_ablate.so")
 
 
 def flags(ablations=False):
-    return ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+    return ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical",
             *(["-DNMI_BUILD_ABLATIONS"] if ablations else []),
             "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"), "-I" + os.path.join(PKG, "host")]
 

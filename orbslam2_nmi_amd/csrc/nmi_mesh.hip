@@ -691,7 +691,6 @@ __global__ __launch_bounds__(kTileThreads) void nmi_mesh_tile_kernel(const float
                                                                      int height, MeshTexture tex, BinGrid g)
 {
     __shared__ TileLds lds;
-    constexpr int kWaves = kTileThreads / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = g.tiles_x * g.tiles_y;
     const int bin = blockIdx.x;

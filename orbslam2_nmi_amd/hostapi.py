@@ -14,7 +14,7 @@ EXPORTED_SYMBOLS = (
     "nmi_properties_default", "nmi_sk_init", "nmi_sk_reset", "nmi_sk_is_middle", "nmi_sk_resize", "nmi_sk_candidates",
     "nmi_sk_format", "nmi_sk_linear_index", "nmi_sk_set_best_from_index", "nmi_find_max_elements",
     "nmi_calculate_translation", "nmi_calculate_relocalization", "nmi_mat4_inverse", "nmi_relocalize_with_strategy",
-    "nmi_config_parse", "nmi_config_load",
+    "nmi_config_parse", "nmi_config_load", "nmi_map_load_obj", "nmi_map_load_xyz", "nmi_map_load_bmp", "nmi_map_free",
 )
 
 
@@ -99,6 +99,12 @@ def _lib():
                                                      C.c_void_p, C.POINTER(StrategyOutput)]
         lib.nmi_config_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Config)]
         lib.nmi_config_load.argtypes = [C.c_char_p, C.POINTER(Config)]
+        fpp, i64p = C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int64)
+        lib.nmi_map_load_obj.argtypes = [C.c_char_p, fpp, fpp, i64p]
+        lib.nmi_map_load_xyz.argtypes = [C.c_char_p, C.c_char_p, fpp, fpp, fpp, i64p]
+        lib.nmi_map_load_bmp.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        lib.nmi_map_free.argtypes = [C.c_void_p]
+        lib.nmi_map_free.restype = None
         _configured = True
     return lib
 
@@ -189,6 +195,41 @@ def config_load(path):
     if rc != 0:
         raise ValueError(f"nmi_config_load({path}) failed: {rc}")
     return cfg
+
+
+def _take(ptr, shape, dtype):
+    """Copy of a malloc'ed C array as numpy, and the C array released."""
+    n = int(np.prod(shape))
+    out = np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype).reshape(shape) if n else np.zeros(shape, dtype)
+    _lib().nmi_map_free(C.cast(ptr, C.c_void_p))
+    return out
+
+
+def load_obj(path):
+    """loadOBJ (objloader.cpp:140-224) -> (xyz float32 [3T,3], uv float32 [3T,2]): the per-corner arrays of nmi_render_mesh."""
+    xyz, uv, n = C.POINTER(C.c_float)(), C.POINTER(C.c_float)(), C.c_int64()
+    rc = _lib().nmi_map_load_obj(str(path).encode(), C.byref(xyz), C.byref(uv), C.byref(n))
+    if rc != 0:
+        raise ValueError(f"nmi_map_load_obj({path}) failed: {rc}")
+    return _take(xyz, (n.value, 3), np.float32), _take(uv, (n.value, 2), np.float32)
+
+
+def load_xyz(path, offset_path):
+    """loadXYZ (objloader.cpp:226-264) -> (xyz float32 [N,3], red float32 [N], rgb float32 [N,3]); red is what nmi_render_points takes."""
+    xyz, red, rgb, n = C.POINTER(C.c_float)(), C.POINTER(C.c_float)(), C.POINTER(C.c_float)(), C.c_int64()
+    rc = _lib().nmi_map_load_xyz(str(path).encode(), str(offset_path).encode(), C.byref(xyz), C.byref(red), C.byref(rgb), C.byref(n))
+    if rc != 0:
+        raise ValueError(f"nmi_map_load_xyz({path}) failed: {rc}")
+    return _take(xyz, (n.value, 3), np.float32), _take(red, (n.value,), np.float32), _take(rgb, (n.value, 3), np.float32)
+
+
+def load_bmp(path):
+    """loadBMP_custom (texture.cpp:31-86) -> uint8 [H,W,3] in file order: the image nmi_texture_create takes."""
+    rgb, w, h = C.POINTER(C.c_uint8)(), C.c_int32(), C.c_int32()
+    rc = _lib().nmi_map_load_bmp(str(path).encode(), C.byref(rgb), C.byref(w), C.byref(h))
+    if rc != 0:
+        raise ValueError(f"nmi_map_load_bmp({path}) failed: {rc}")
+    return _take(rgb, (h.value, w.value, 3), np.uint8)
 
 
 def relocalize_with_strategy(Tcw, initial, eval_grid, distance=(0, 0, 0), rotation=(0, 0, 0), not_initialized=False,
