@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "nmi_hip.h"
@@ -90,34 +91,136 @@ static float surface_grey(float u, float v, float n)
     return fminf(fmaxf(t, 0.0f), 255.0f);
 }
 
+// --write-files DIR: the synthetic map as the files the reference's loaders read (OBJ + BMP, or XYZ + offset) and a settings file
+// in the reference's YAML format that names them.  Numbers are printed with enough digits to come back bit for bit.
+static bool write_files(const char *dir, bool mesh, int mesh_nx, int mesh_ny, const std::vector<float> &xyz, const std::vector<float> &attr,
+                        const std::vector<uint8_t> &rgb, int tw, int th)
+{
+    const std::string d = std::string(dir) + "/";
+    FILE *y = fopen((d + "settings.yaml").c_str(), "w");
+    if (!y) return false;
+    fprintf(y, "%%YAML:1.0\n\nCamera.fx: %.17g\nCamera.fy: %.17g\nCamera.cx: %.17g\nCamera.cy: %.17g\nCamera.Width: %d\nCamera.Height: %d\n\n", FX, FY, CX,
+            CY, W, H);
+    fprintf(y, "NMI.Treshold: 0.05\nNMI.SynthNumX: 3\nNMI.SynthNumY: 3\nNMI.SynthNumZ: 3\nNMI.WarpNumX: 3\nNMI.WarpNumY: 3\nNMI.WarpNumZ: 3\n");
+    fprintf(y, "NMI.SynthStepX: 0.2\nNMI.SynthStepY: 0.2\nNMI.SynthStepZ: 0.5\nNMI.WarpStepX: 0.02\nNMI.WarpStepY: 0.02\nNMI.WarpStepZ: 0.05\n\n");
+    fprintf(y, "NMI.Render.PointSize: 3.0\nNMI.Render.NearPlane: 5.0\nNMI.Render.FarPlane: 30.0\n");
+    if (mesh)
+        fprintf(y, "NMI.Render.Object: \"map.obj\"\nNMI.Render.Texture: \"map.bmp\"\n");
+    else
+        fprintf(y, "NMI.Render.Cloud: \"map.xyz\"\nNMI.Render.Offset: \"map.offset\"\n");
+    fclose(y);
+    if (mesh) {
+        FILE *o = fopen((d + "map.obj").c_str(), "w");
+        if (!o) return false;
+        fprintf(o, "# %d x %d quads of the level_pipeline surface\n", mesh_nx, mesh_ny);
+        // one v / vt per grid node, taken from the first corner that uses it; faces index them (1-based), as an exporter would write
+        std::vector<int> node((size_t)(mesh_nx + 1) * (mesh_ny + 1), -1);
+        std::vector<int> index(attr.size() / 2);
+        int count = 0;
+        for (size_t k = 0; k < attr.size() / 2; ++k) {
+            const int i = (int)lrintf(attr[2 * k] * mesh_nx), j = (int)lrintf(attr[2 * k + 1] * mesh_ny);
+            int &n = node[(size_t)j * (mesh_nx + 1) + i];
+            if (n < 0) {
+                n = ++count;
+                fprintf(o, "v %.9g %.9g %.9g\nvt %.9g %.9g\n", xyz[3 * k], xyz[3 * k + 1], xyz[3 * k + 2], attr[2 * k], attr[2 * k + 1]);
+            }
+            index[k] = n;
+        }
+        for (size_t k = 0; k + 2 < index.size(); k += 3) fprintf(o, "f %d/%d %d/%d %d/%d\n", index[k], index[k], index[k + 1], index[k + 1], index[k + 2], index[k + 2]);
+        fclose(o);
+        FILE *b = fopen((d + "map.bmp").c_str(), "wb");
+        if (!b) return false;
+        unsigned char h[54] = {'B', 'M'};
+        auto put = [&](int at, uint32_t v) { h[at] = v & 255, h[at + 1] = (v >> 8) & 255, h[at + 2] = (v >> 16) & 255, h[at + 3] = (v >> 24) & 255; };
+        put(0x02, 54 + (uint32_t)rgb.size()), put(0x0A, 54), put(0x0E, 40), put(0x12, (uint32_t)tw), put(0x16, (uint32_t)th), put(0x1A, 1 | (24u << 16));
+        put(0x22, (uint32_t)rgb.size());
+        fwrite(h, 1, 54, b), fwrite(rgb.data(), 1, rgb.size(), b);
+        fclose(b);
+    } else {
+        const double off[3] = {2683000.25, 1250000.5, 400.0};  // (a survey frame's size of numbers: what the offset file is for)
+        FILE *f = fopen((d + "map.offset").c_str(), "w");
+        if (!f) return false;
+        fprintf(f, "%.17g %.17g %.17g\n", off[0], off[1], off[2]);
+        fclose(f);
+        f = fopen((d + "map.xyz").c_str(), "w");
+        if (!f) return false;
+        for (size_t k = 0; k < attr.size(); ++k)
+            fprintf(f, "%.17g %.17g %.17g %.9g 0 0\n", (double)xyz[3 * k] + off[0], (double)xyz[3 * k + 1] + off[1], (double)xyz[3 * k + 2] + off[2],
+                    attr[k] * 256.0f);
+        fclose(f);
+    }
+    return true;
+}
+
 int main(int argc, char **argv)
 {
-    // usage: level_pipeline [keyframes] [--mesh [NXxNY]]   (--mesh: nmi_prop_RENDER 1, the reference's default render mode:
-    // the same surface as NX x NY quads = 2 NX NY textured triangles, default 300x200 = 120,000)
+    // usage: level_pipeline [keyframes] [--mesh [NXxNY]] [--density D] [--write-files DIR | --files DIR]
+    //   --mesh: nmi_prop_RENDER 1, the reference's default render mode: the same surface as NX x NY quads = 2 NX NY textured
+    //           triangles, default 300x200 = 120,000;  --density: points per pixel of a view along each axis (cloud; default 0.9)
+    //   --write-files DIR: write the map and a settings file into DIR and stop (no GPU needed)
+    //   --files DIR: take camera, grid, render parameters and the map from DIR/settings.yaml and the files it names
+    //           (nmi_config_load, nmi_map_load_obj / _bmp / _xyz) instead of building them in memory
     int keyframes = 200, mesh_nx = 0, mesh_ny = 0;
+    float density = 0.9f;
+    const char *write_dir = nullptr, *read_dir = nullptr;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--mesh")) {
             mesh_nx = 300, mesh_ny = 200;
             if (i + 1 < argc && sscanf(argv[i + 1], "%dx%d", &mesh_nx, &mesh_ny) == 2) ++i;
+        } else if (!strcmp(argv[i], "--density") && i + 1 < argc) {
+            density = (float)atof(argv[++i]);
+        } else if (!strcmp(argv[i], "--write-files") && i + 1 < argc) {
+            write_dir = argv[++i];
+        } else if (!strcmp(argv[i], "--files") && i + 1 < argc) {
+            read_dir = argv[++i];
         } else {
             keyframes = atoi(argv[i]);
         }
     }
-    const bool mesh = mesh_nx > 0 && mesh_ny > 0;
-    nmi_params prm;
-    CHECK_NMI(nmi_params_default(&prm, W, H));
-    nmi_ctx *ctx = nullptr;
-    CHECK_NMI(nmi_create(&prm, &ctx));
+    bool mesh = mesh_nx > 0 && mesh_ny > 0;
 
     // The map: a textured, undulating surface about 10 m ahead, three frame-widths wide, ~0.8 points per pixel of a view
     // (3 M points).
     // (relief of +-3 m: on a flat wall a sideways step and a small turn of the camera move the image alike, and the 6-D search
     // could not tell them apart)
     std::vector<float> xyz, red;  // point cloud: positions [N][3] + red [N]; mesh: corners [3T][3] + uv [3T][2]
-    nmi_texture *tex = nullptr;
+    std::vector<uint8_t> rgb;     // mesh: the texture, RGB8
+    int tw = 0, th = 0;
+    nmi_config cfg;
+    memset(&cfg, 0, sizeof cfg);
     unsigned s = 2468u;
-    if (!mesh) {
-        const int nu = (int)(3 * W * 0.9), nv = (int)(3 * H * 0.9);
+    if (read_dir) {
+        const std::string d = std::string(read_dir) + "/";
+        const int rc = nmi_config_load((d + "settings.yaml").c_str(), &cfg);
+        if (rc != 0 || cfg.width != W || cfg.height != H) {
+            fprintf(stderr, "settings.yaml: rc %d, %d x %d (this program is built for %d x %d)\n", rc, cfg.width, cfg.height, W, H);
+            return 1;
+        }
+        auto at = [&](const char *name) { return name[0] == '/' ? std::string(name) : d + name; };
+        mesh = cfg.render_object[0] != 0;
+        float *a = nullptr, *b = nullptr;
+        int64_t n = 0;
+        if (mesh) {
+            uint8_t *img = nullptr;
+            int32_t w32 = 0, h32 = 0;
+            if (nmi_map_load_obj(at(cfg.render_object).c_str(), &a, &b, &n) != 0 || nmi_map_load_bmp(at(cfg.render_texture).c_str(), &img, &w32, &h32) != 0) {
+                fprintf(stderr, "cannot read the mesh / its texture\n");
+                return 1;
+            }
+            xyz.assign(a, a + n * 3), red.assign(b, b + n * 2), rgb.assign(img, img + (size_t)w32 * h32 * 3);
+            tw = w32, th = h32, mesh_nx = 0, mesh_ny = 0;
+            nmi_map_free(img);
+        } else {
+            if (nmi_map_load_xyz(at(cfg.render_cloud).c_str(), at(cfg.render_offset).c_str(), &a, &b, nullptr, &n) != 0) {
+                fprintf(stderr, "cannot read the cloud / its offset\n");
+                return 1;
+            }
+            xyz.assign(a, a + n * 3), red.assign(b, b + n);
+        }
+        nmi_map_free(a), nmi_map_free(b);
+        printf("map from %s: %lld %s\n", read_dir, (long long)(mesh ? n / 3 : n), mesh ? "triangles" : "points");
+    } else if (!mesh) {
+        const int nu = (int)(3 * W * density), nv = (int)(3 * H * density);
         xyz.resize((size_t)nu * nv * 3), red.resize((size_t)nu * nv);
         for (int j = 0; j < nv; ++j)
             for (int i = 0; i < nu; ++i) {
@@ -132,8 +235,8 @@ int main(int argc, char **argv)
             }
     } else {
         // texture: the surface's grey values on a 2048 x 1024 raster (what loadBMP_custom would hand to glTexImage2D, texture.cpp:31-86)
-        const int tw = 2048, th = 1024;
-        std::vector<uint8_t> rgb((size_t)tw * th * 3);
+        tw = 2048, th = 1024;
+        rgb.resize((size_t)tw * th * 3);
         for (int j = 0; j < th; ++j)
             for (int i = 0; i < tw; ++i) {
                 const float u = -W + 3.0f * W * (i + 0.5f) / tw, v = -H + 3.0f * H * (j + 0.5f) / th;
@@ -141,7 +244,6 @@ int main(int argc, char **argv)
                 const uint8_t g = (uint8_t)lrintf(surface_grey(u, v, ((s >> 8) & 0xFFFF) / 65535.0f - 0.5f));
                 rgb[((size_t)j * tw + i) * 3] = rgb[((size_t)j * tw + i) * 3 + 1] = rgb[((size_t)j * tw + i) * 3 + 2] = g;
             }
-        CHECK_NMI(nmi_texture_create(ctx, rgb.data(), tw, th, &tex));
         xyz.resize((size_t)mesh_nx * mesh_ny * 6 * 3), red.resize((size_t)mesh_nx * mesh_ny * 6 * 2);
         size_t k = 0;
         auto corner = [&](int i, int j) {
@@ -156,7 +258,18 @@ int main(int argc, char **argv)
                 corner(i, j), corner(i, j + 1), corner(i + 1, j + 1);
             }
     }
-    const int64_t n_prims = mesh ? (int64_t)mesh_nx * mesh_ny * 2 : (int64_t)red.size();
+    if (write_dir) {
+        const bool ok = write_files(write_dir, mesh, mesh_nx, mesh_ny, xyz, red, rgb, tw, th);
+        printf("%s\n", ok ? "FILES WRITTEN" : "FILES FAILED");
+        return ok ? 0 : 1;
+    }
+    nmi_params prm;
+    CHECK_NMI(nmi_params_default(&prm, W, H));
+    nmi_ctx *ctx = nullptr;
+    CHECK_NMI(nmi_create(&prm, &ctx));
+    nmi_texture *tex = nullptr;
+    if (mesh) CHECK_NMI(nmi_texture_create(ctx, rgb.data(), tw, th, &tex));
+    const int64_t n_prims = mesh ? (int64_t)(xyz.size() / 9) : (int64_t)red.size();
     float *d_xyz = nullptr, *d_red = nullptr;
     uint8_t *d_frame = nullptr, *d_tmp = nullptr;
     CHECK_HIP(hipMalloc((void **)&d_xyz, xyz.size() * sizeof(float)));
@@ -168,6 +281,7 @@ int main(int argc, char **argv)
 
     Pipeline p;
     p.rp = nmi_render_params{FX, FY, CX, CY, 5.0f, 30.0f, 3.0f};
+    if (read_dir) p.rp = nmi_render_params{cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.render_near, cfg.render_far, cfg.render_point_size};
 
     // The tracker's pose: camera at the origin, ORB-SLAM axes (x right, y down, z forward) = world axes.
     float Twc0[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
@@ -212,6 +326,7 @@ int main(int argc, char **argv)
     CHECK_NMI(nmi_mat4_inverse(Twc0, in.Tcw));
     in.nmi_threshold = 0.05f;
     in.initial = initial.to_c();
+    if (read_dir) in.nmi_threshold = cfg.nmi_threshold, in.initial = cfg.initial;
     nmi_properties props;
     nmi_properties_default(&props);
     nmi_strategy_output out;
