@@ -320,9 +320,9 @@ __device__ __forceinline__ void tri_planes(const TriView &t, const float (&tu)[3
 
 // The fragment shader: uv at the pixel and at its right and upper neighbours (one reciprocal of Q each), level of detail,
 // GL_LINEAR / GL_LINEAR_MIPMAP_LINEAR sample of the luma pyramid -> grey level 0..255.
-__device__ __forceinline__ uint32_t shade_pixel(const Planes &P, const float *__restrict__ luma_base, const TexLevel *levels, int n_levels,
-                                            float fxp, float fyp)
-{
+__device__ __forceinline__ uint32_t shade_pixel(const Planes &P, const float *__restrict__ luma_base, const TexLevel &base, const TexLevel *levels,
+                                            int n_levels, float fxp, float fyp)
+{   // (`base` = levels[0] held by the caller in registers -- for the tile kernel in scalar ones, straight from its arguments)
     // S = (s0 + sx dx) + sy dy, R and Q likewise; u = S / Q at the pixel, at its right neighbour (S + sx, Q + qx) and at its upper one.
     // S and R go as a pair through the packed fp32 instructions; the three reciprocals are warp_rcp's (the division's bits).
     const float dx = fxp - P.xr, dy = fyp - P.yr;
@@ -336,22 +336,27 @@ __device__ __forceinline__ uint32_t shade_pixel(const Planes &P, const float *__
         iq = 1.0f / Q, iqx = 1.0f / Qx, iqy = 1.0f / Qy;
     const v2f uv = SR * iq;
     const v2f uvx = (SR + P.srx) * iqx, uvy = (SR + P.sry) * iqy;
-    const v2f twh = {levels[0].w, levels[0].h};
+    const v2f twh = {base.w, base.h};
     const v2f ddx = (uvx - uv) * twh, ddy = (uvy - uv) * twh;   // (du/dx tw, dv/dx th), (du/dy tw, dv/dy th)
     // lambda = log2(rho), rho = the longer of the two footprint axes: log2 of a square root is half the log2 of the square
     const v2f sqx = ddx * ddx, sqy = ddy * ddy;
     const float rho2 = fmaxf(sqx.x + sqx.y, sqy.x + sqy.y);
-    const float lambda = 0.5f * log2f(rho2);
-    // magnification (lambda <= 0, or NaN): GL_LINEAR on the base level; minification: GL_LINEAR_MIPMAP_LINEAR between levels
-    // floor(lambda) and the next.  One code path: with lambda clamped to 0 the lower level is the base level, and the upper
-    // level is fetched only where it has weight.
-    const float lc = fminf(fmaxf(lambda, 0.0f), (float)(n_levels - 1));
-    const int l0 = (int)floorf(lc), l1 = min(l0 + 1, n_levels - 1);
-    const float f = lc - (float)l0;
-    float luma = tex_bilinear(luma_base, levels[l0], uv);
-    if (lambda > 0.0f) {
-        const float s1 = tex_bilinear(luma_base, levels[l1], uv);
-        luma = luma + (s1 - luma) * f;
+    float luma;
+    if (!(rho2 > 1.0f)) {
+        // magnification (lambda = log2(rho2) / 2 <= 0, or NaN): GL_LINEAR on the base level -- no logarithm, no level arithmetic,
+        // no look-up in the level table
+        luma = tex_bilinear(luma_base, base, uv);
+    } else {
+        // minification: GL_LINEAR_MIPMAP_LINEAR between levels floor(lambda) and the next (lambda clamped to the pyramid)
+        const float lambda = 0.5f * log2f(rho2);
+        const float lc = fminf(fmaxf(lambda, 0.0f), (float)(n_levels - 1));
+        const int l0 = (int)floorf(lc), l1 = min(l0 + 1, n_levels - 1);
+        const float f = lc - (float)l0;
+        luma = tex_bilinear(luma_base, levels[l0], uv);
+        if (lambda > 0.0f) {
+            const float s1 = tex_bilinear(luma_base, levels[l1], uv);
+            luma = luma + (s1 - luma) * f;
+        }
     }
     return (uint32_t)(fminf(fmaxf(luma, 0.0f), 1.0f) * 255.0f + 0.5f);
 }
@@ -861,6 +866,8 @@ __global__ __launch_bounds__(kTileThreads) void nmi_mesh_tile_kernel(const float
         __syncthreads();
     }
     if (!col_ok) return;
+    TexLevel base_level;
+    tex_level_fill(tex, 0, &base_level);   // from the kernel's arguments: scalar registers
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int y = oy + 32 * half;
@@ -901,7 +908,7 @@ __global__ __launch_bounds__(kTileThreads) void nmi_mesh_tile_kernel(const float
                 if (setup_piece(xyz, uv, (long long)(id >> 1), (int)(id & 1ull), mvps + s * 16, width, height, t, su, sv)) {  // (true: it produced this key)
                     Planes P;
                     tri_planes(t, su, sv, P);
-                    grey = shade_pixel(P, tex.luma, lds.tex, tex.levels, (float)(ox + k) + 0.5f, (float)y + 0.5f);
+                    grey = shade_pixel(P, tex.luma, base_level, lds.tex, tex.levels, (float)(ox + k) + 0.5f, (float)y + 0.5f);
                 }
                 packed = (packed & ~(0xFFu << (8 * k))) | (grey << (8 * k));
                 keys[3] = kEmptyKey;  // done
@@ -914,7 +921,7 @@ __global__ __launch_bounds__(kTileThreads) void nmi_mesh_tile_kernel(const float
             if ((key != kEmptyKey) & (ox + k < width) & !(g.dbg & 1)) {
                 Planes P;
                 planes_from_lds(lds.rec[(uint32_t)(key & 0x1FFu)], P);
-                const uint32_t grey = shade_pixel(P, tex.luma, lds.tex, tex.levels, (float)(ox + k) + 0.5f, (float)y + 0.5f);
+                const uint32_t grey = shade_pixel(P, tex.luma, base_level, lds.tex, tex.levels, (float)(ox + k) + 0.5f, (float)y + 0.5f);
                 packed = (packed & ~(0xFFu << (8 * k))) | (grey << (8 * k));
             }
         }

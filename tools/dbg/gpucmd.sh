@@ -1,9 +1,10 @@
-O=$GRAFT_REPO_ROOT/gpurun_out/r03_bf; mkdir -p $O
-timeout -k 10 600 python3 -m pytest tests/test_render.py tests/test_config5.py -q -m gpu -x -k "level or cloud or config5 or splat" > $O/tests.log 2>&1; echo rc=$? >> $O/tests.log; tail -3 $O/tests.log
+O=$GRAFT_REPO_ROOT/gpurun_out/r03_bg; mkdir -p $O
+timeout -k 10 500 python3 -m pytest tests/test_render.py -q -m gpu -x > $O/tests.log 2>&1; echo rc=$? >> $O/tests.log; tail -3 $O/tests.log
 cd /tmp && export TMPDIR=/tmp
-for v in old new old new; do
+for v in old new; do
+for m in "60 40" "300 200"; do
   export NMI_HIP_LIBRARY=$GRAFT_REPO_ROOT/build/ab/$v.so
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$v -- $GRAFT_REPO_ROOT/examples/level_pipeline 100 > $O/$v.log 2>&1
-  echo "$v $(grep -h front_kernel $(find $O/$v -name '*kernel_stats.csv') | awk -F, '{print $(NF-4)}' | tail -1) $(tail -2 $O/$v.log | head -1 | grep -o '[0-9.]* levels/s')"
-  rm -rf $O/$v
-done
+  tag=${v}_$(echo $m | tr ' ' x)
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$tag -- python3 $GRAFT_REPO_ROOT/tools/mesh_profile.py $m 20 > $O/$tag.log 2>&1
+  echo "$v mesh $m $(grep -h 'mesh_tile_kernel' $(find $O/$tag -name '*kernel_stats.csv') | awk -F, '{printf "%s %.1f  ", substr($1,7,18), $(NF-4)/1000}')"
+done; done
