@@ -1,6 +1,7 @@
 // ASan/UBSan exercise of the host-side C++ (no GPU): YAML reader on hostile inputs, grid arithmetic, strategy state
 // machine with odd callbacks.  Built and run by tests/test_host_sanitizers.py with -fsanitize=address,undefined.
 #include <math.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -91,6 +92,48 @@ int main()
     if (nmi_relocalize_with_strategy(&sing, nullptr, eval_cb, &calls, &out) == 0) return 7;
     float inv[16], zero[16] = {0};
     if (nmi_mat4_inverse(zero, inv) == 0) return 8;
+    // 4. map files: every truncation and random corruption of a small OBJ / XYZ / BMP must load or fail cleanly
+    {
+        const char *dir = getenv("TMPDIR") ? getenv("TMPDIR") : "/tmp";
+        const std::string path = std::string(dir) + "/nmi_host_sanitize_map.bin", off = std::string(dir) + "/nmi_host_sanitize_map.offset";
+        auto put = [&](const std::string &name, const std::string &bytes) {
+            FILE *f = fopen(name.c_str(), "wb");
+            if (f) fwrite(bytes.data(), 1, bytes.size(), f), fclose(f);
+        };
+        const std::string obj = "# c\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nvn 0 0 1\nf 1/1 2/2 3/3\nf 3/3 2/2 1/1\n";
+        const std::string xyz = "10 20 30 255 0 0\n11 21 31 128 64 32\n12 22 32 1 2 3\n";
+        std::string bmp_w(54 + 4 * 4 * 3, '\x7f');
+        bmp_w[0] = 'B', bmp_w[1] = 'M';
+        for (int i = 2; i < 54; ++i) bmp_w[i] = 0;
+        bmp_w[0x0A] = 54, bmp_w[0x12] = 4, bmp_w[0x16] = 4, bmp_w[0x1A] = 1, bmp_w[0x1C] = 24, bmp_w[0x22] = 48;
+        const std::string bmp = bmp_w;
+        put(off, "1 2 3\n");
+        float *a = nullptr, *b = nullptr;
+        uint8_t *img = nullptr;
+        int64_t n = 0;
+        int32_t w = 0, h = 0;
+        auto try_all = [&](const std::string &bytes) {
+            put(path, bytes);
+            if (nmi_map_load_obj(path.c_str(), &a, &b, &n) == 0) nmi_map_free(a), nmi_map_free(b);
+            if (nmi_map_load_xyz(path.c_str(), off.c_str(), &a, &b, nullptr, &n) == 0) nmi_map_free(a), nmi_map_free(b);
+            if (nmi_map_load_bmp(path.c_str(), &img, &w, &h) == 0) nmi_map_free(img);
+        };
+        put(path, obj);
+        if (nmi_map_load_obj(path.c_str(), &a, &b, &n) != 0 || n != 6) return 9;
+        nmi_map_free(a), nmi_map_free(b);
+        put(path, bmp);
+        if (nmi_map_load_bmp(path.c_str(), &img, &w, &h) != 0 || w != 4 || h != 4) return 10;
+        nmi_map_free(img);
+        for (const std::string *src : {&obj, &xyz, &bmp}) {
+            for (size_t cut = 0; cut <= src->size(); cut += 2) try_all(src->substr(0, cut));
+            for (int it = 0; it < 300; ++it) {
+                std::string s(*src);
+                for (int k = 0; k < 1 + (int)(rnd() % 4); ++k) s[rnd() % s.size()] = (char)(rnd() & 0xFF);
+                try_all(s);
+            }
+        }
+        remove(path.c_str()), remove(off.c_str());
+    }
     puts("host sanitize ok");
     return 0;
 }

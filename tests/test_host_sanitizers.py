@@ -1,4 +1,4 @@
-"""AddressSanitizer + UBSan run of the host-side C++ (YAML reader, grid arithmetic, strategy) on hostile inputs.
+"""AddressSanitizer + UBSan run of the host-side C++ (YAML reader, grid arithmetic, strategy, map-file loaders) on hostile inputs.
 CPU only (GPU sanitizers are not available on the pool)."""
 import os
 import subprocess
@@ -10,12 +10,13 @@ def test_host_code_under_asan_ubsan(tmp_path):
     exe = tmp_path / "host_sanitize"
     srcs = [os.path.join(ROOT, "tests", "native", "host_sanitize.cpp"),
             os.path.join(ROOT, "orbslam2_nmi_amd", "host", "nmi_driver.cpp"),
-            os.path.join(ROOT, "orbslam2_nmi_amd", "host", "nmi_yaml.cpp")]
+            os.path.join(ROOT, "orbslam2_nmi_amd", "host", "nmi_yaml.cpp"),
+            os.path.join(ROOT, "orbslam2_nmi_amd", "host", "nmi_map.cpp")]
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
                            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "orbslam2_nmi_amd", "host"),
                            *srcs, "-o", str(exe)])
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300,
-                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", TMPDIR=str(tmp_path)))
     assert r.returncode == 0, r.stdout + r.stderr
     assert "host sanitize ok" in r.stdout
 
