@@ -1,3 +1,4 @@
-O=$GRAFT_REPO_ROOT/gpurun_out/r03_bh; mkdir -p $O
-timeout -k 10 1000 python3 -m pytest tests -q -m gpu -x > $O/tests.log 2>&1; echo rc=$? >> $O/tests.log; tail -5 $O/tests.log
-timeout -k 10 120 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
+for v in old new old new; do
+  export NMI_HIP_LIBRARY=$GRAFT_REPO_ROOT/build/ab/$v.so
+  echo "== $v"; python3 tools/producer_time.py 2>&1 | grep "point render"
+done
