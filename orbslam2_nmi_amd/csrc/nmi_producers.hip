@@ -489,75 +489,78 @@ hipError_t launch_level_front_points(const void *packed, long long npoints, cons
 }
 
 // Six planes (a, b, c, d; a x + b y + c z + d >= 0 inside) that hold the frusta of all S views (column-major MVP matrices): per
-// side of the clip volume the views' own planes (row 3 +- row j) are averaged to one direction and pushed out until all 8 S
+// side of the clip volume the views' own planes (row 3 +- row j) are summed to one direction and pushed out until all 8 S
 // frustum corners (the corners of clip space taken back through each inverse matrix, double precision) lie inside, plus a margin
 // far above the rounding of either side's test.  A view draws only inside the hull of its corners, hence inside all six.
 // A matrix that cannot be inverted, or a corner at infinity, gives six zero planes (nothing culled).
 void level_views_bound(const float *mvps, int S, float out[24])
 {
+    // (On the host's critical path between two levels: written to cost ~2 us for 27 views -- no division per component, the
+    // adjugate instead of the inverse: a corner is adj(M) (+-1, +-1, +-1, 1) up to a factor that cancels in p.xyz / p.w.)
     for (int k = 0; k < 24; ++k) out[k] = 0.0f;
     if (S <= 0 || S > 64) return;
     double corners[64 * 8][3];
     double dir[6][3] = {};
+    double reach = 0.0;
     for (int s = 0; s < S; ++s) {
-        double m[16], inv[16];
+        double m[16];
         for (int k = 0; k < 16; ++k) m[k] = mvps[(size_t)s * 16 + k];
-        // cofactor inverse of a 4x4
-        inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
-        inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
-        inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
-        inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
-        inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
-        inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
-        inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
-        inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
-        inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
-        inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
-        inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
-        inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
-        inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
-        inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
-        inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
-        inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
-        const double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+        // adjugate through the twelve 2x2 minors of the upper and lower row pairs (a(r, c) = m[c * 4 + r]): ~110 operations
+        const double a00 = m[0], a10 = m[1], a20 = m[2], a30 = m[3], a01 = m[4], a11 = m[5], a21 = m[6], a31 = m[7];
+        const double a02 = m[8], a12 = m[9], a22 = m[10], a32 = m[11], a03 = m[12], a13 = m[13], a23 = m[14], a33 = m[15];
+        const double s0 = a00 * a11 - a10 * a01, s1 = a00 * a12 - a10 * a02, s2 = a00 * a13 - a10 * a03;
+        const double s3 = a01 * a12 - a11 * a02, s4 = a01 * a13 - a11 * a03, s5 = a02 * a13 - a12 * a03;
+        const double c5 = a22 * a33 - a32 * a23, c4 = a21 * a33 - a31 * a23, c3 = a21 * a32 - a31 * a22;
+        const double c2 = a20 * a33 - a30 * a23, c1 = a20 * a32 - a30 * a22, c0 = a20 * a31 - a30 * a21;
+        const double det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
         if (!(fabs(det) > 1e-300)) return;
+        const double adj[4][4] = {   // adj[r][c]: row r of det * inverse
+            {a11 * c5 - a12 * c4 + a13 * c3, -a01 * c5 + a02 * c4 - a03 * c3, a31 * s5 - a32 * s4 + a33 * s3, -a21 * s5 + a22 * s4 - a23 * s3},
+            {-a10 * c5 + a12 * c2 - a13 * c1, a00 * c5 - a02 * c2 + a03 * c1, -a30 * s5 + a32 * s2 - a33 * s1, a20 * s5 - a22 * s2 + a23 * s1},
+            {a10 * c4 - a11 * c2 + a13 * c0, -a00 * c4 + a01 * c2 - a03 * c0, a30 * s4 - a31 * s2 + a33 * s0, -a20 * s4 + a21 * s2 - a23 * s0},
+            {-a10 * c3 + a11 * c1 - a12 * c0, a00 * c3 - a01 * c1 + a02 * c0, -a30 * s3 + a31 * s1 - a32 * s0, a20 * s3 - a21 * s1 + a22 * s0}};
         for (int c = 0; c < 8; ++c) {
-            const double x = (c & 1) ? 1.0 : -1.0, y = (c & 2) ? 1.0 : -1.0, z = (c & 4) ? 1.0 : -1.0;
             double p[4];
-            for (int r = 0; r < 4; ++r) p[r] = (inv[r] * x + inv[4 + r] * y + inv[8 + r] * z + inv[12 + r]) / det;
+            for (int r = 0; r < 4; ++r)
+                p[r] = (((c & 1) ? adj[r][0] : -adj[r][0]) + ((c & 2) ? adj[r][1] : -adj[r][1])) + (((c & 4) ? adj[r][2] : -adj[r][2]) + adj[r][3]);
+            const double big = fabs(p[0]) + fabs(p[1]) + fabs(p[2]);
+            if (!(fabs(p[3]) > 1e-30 * big) || !(fabs(p[3]) > 0.0)) return;   // a corner at infinity (also false for NaN)
+            const double iw = 1.0 / p[3];
+            double *q = corners[s * 8 + c];
+            q[0] = p[0] * iw, q[1] = p[1] * iw, q[2] = p[2] * iw;
+            const double size = fabs(q[0]) + fabs(q[1]) + fabs(q[2]);
+            if (!(size < 1e30)) return;   // (false for NaN too)
+            reach = size > reach ? size : reach;
             // a corner must lie in front of its own view (w_clip > 0): a matrix with the volume turned inside out is not a camera
-            if (!(p[3] == p[3]) || !(fabs(p[3]) > 1e-12)) return;
-            for (int k = 0; k < 3; ++k) {
-                const double v = p[k] / p[3];
-                if (!(v == v) || fabs(v) > 1e30) return;
-                corners[s * 8 + c][k] = v;
-            }
-            const double *q = corners[s * 8 + c];
-            const double wc = m[3] * q[0] + m[7] * q[1] + m[11] * q[2] + m[15];
-            if (!(wc > 0.0)) return;
+            if (!(m[3] * q[0] + m[7] * q[1] + m[11] * q[2] + m[15] > 0.0)) return;
         }
-        for (int k = 0; k < 6; ++k) {  // plane k of this view: row 3 + row j (k even) or row 3 - row j (k odd), j = k / 2
+        // plane k of this view: row 3 + row j (k even) or row 3 - row j (k odd), j = k / 2.  The views' planes are added up as
+        // they are (same projection, so alike in length): any common direction is valid, a good one is tight.
+        for (int k = 0; k < 6; ++k) {
             const int j = k >> 1;
             const double sg = (k & 1) ? -1.0 : 1.0;
-            const double a = m[3] + sg * m[j], b = m[7] + sg * m[4 + j], c = m[11] + sg * m[8 + j];
-            const double len = sqrt(a * a + b * b + c * c);
-            if (!(len > 1e-300)) return;
-            dir[k][0] += a / len, dir[k][1] += b / len, dir[k][2] += c / len;
+            dir[k][0] += m[3] + sg * m[j], dir[k][1] += m[7] + sg * m[4 + j], dir[k][2] += m[11] + sg * m[8 + j];
+        }
+    }
+    double n[6][3], least[6];
+    for (int k = 0; k < 6; ++k) {
+        const double len2 = dir[k][0] * dir[k][0] + dir[k][1] * dir[k][1] + dir[k][2] * dir[k][2];
+        if (!(len2 > 1e-60) || !(len2 < 1e300)) return;  // the views face every which way (or a matrix is not finite): no common side
+        const double il = 1.0 / sqrt(len2);
+        n[k][0] = dir[k][0] * il, n[k][1] = dir[k][1] * il, n[k][2] = dir[k][2] * il;
+        least[k] = 1e300;
+    }
+    for (int i = 0; i < S * 8; ++i) {   // one pass over the corners, six running minima
+        const double x = corners[i][0], y = corners[i][1], z = corners[i][2];
+        for (int k = 0; k < 6; ++k) {
+            const double v = n[k][0] * x + n[k][1] * y + n[k][2] * z;
+            least[k] = v < least[k] ? v : least[k];
         }
     }
     float planes[24];
     for (int k = 0; k < 6; ++k) {
-        const double len = sqrt(dir[k][0] * dir[k][0] + dir[k][1] * dir[k][1] + dir[k][2] * dir[k][2]);
-        if (!(len > 1e-6)) return;  // the views face every which way: no common side
-        const double n[3] = {dir[k][0] / len, dir[k][1] / len, dir[k][2] / len};
-        double least = 1e300, reach = 0.0;
-        for (int i = 0; i < S * 8; ++i) {
-            const double v = n[0] * corners[i][0] + n[1] * corners[i][1] + n[2] * corners[i][2];
-            least = v < least ? v : least;
-            reach = fmax(reach, fabs(corners[i][0]) + fabs(corners[i][1]) + fabs(corners[i][2]));
-        }
-        planes[4 * k] = (float)n[0], planes[4 * k + 1] = (float)n[1], planes[4 * k + 2] = (float)n[2];
-        planes[4 * k + 3] = (float)(-least + 1e-4 * reach + 1e-6);
+        planes[4 * k] = (float)n[k][0], planes[4 * k + 1] = (float)n[k][1], planes[4 * k + 2] = (float)n[k][2];
+        planes[4 * k + 3] = (float)(-least[k] + 1e-4 * reach + 1e-6);
     }
     for (int k = 0; k < 24; ++k) out[k] = planes[k];
 }

@@ -1,0 +1,14 @@
+import sys, os, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(sys.path[0], "tests"))
+import importlib.util
+spec = importlib.util.spec_from_file_location("test_render", os.path.join(sys.path[0], "test_render.py"))
+m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+bad = []
+for seed in range(100, 100 + int(sys.argv[1])):
+    try:
+        m.test_gpu_level_cull_by_common_planes_changes_nothing(seed)
+    except AssertionError as e:
+        import traceback
+        tb = traceback.extract_tb(e.__traceback__)[-1]
+        bad.append((seed, tb.lineno, tb.line[:80], str(e)[:80]))
+print("CULL CAMPAIGN", sys.argv[1], "seeds, failures:", bad)

@@ -1,9 +1,4 @@
-O=$GRAFT_REPO_ROOT/gpurun_out/r03_bk; mkdir -p $O
-cd /tmp && export TMPDIR=/tmp
-for L in 500000 1000000 1600000; do
-  export NMI_MESH_BOX_LANES=$L
-  m=300x200
-  rm -rf "$O/trace_$m"
-  rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d "$O/trace_$m" -- python3 "$GRAFT_REPO_ROOT/bench.py" --config e2e --keyframes 20 --map mesh --mesh-quads $m > "$O/trace_$m.log" 2>&1
-  echo "box lanes $L"; python3 "$GRAFT_REPO_ROOT/tools/e2e_timeline.py" "$O/trace_$m" | grep "bin_kernel\|first start"
-done
+O=$GRAFT_REPO_ROOT/gpurun_out/r03_bm; mkdir -p $O
+timeout -k 10 600 python3 -m pytest tests/test_render.py tests/test_config5.py tests/test_level_sharded.py -q -m gpu -x -k "level or cull or config5" > $O/tests.log 2>&1; echo rc=$? >> $O/tests.log; tail -3 $O/tests.log
+timeout -k 10 300 python3 tools/dbg/cull_campaign.py 20 2>&1 | tail -1
+for i in 1 2; do ./examples/level_pipeline 300 | tail -2 | head -1; done
