@@ -278,18 +278,22 @@ __global__ __launch_bounds__(256) void nmi_splat_kernel(const float *__restrict_
 // epoch & 1 -- cleared by the PREVIOUS replay's front kernel -- and its last `clear_blocks` workgroups clear the other one for
 // the next replay.  The 44 MB of stores ride under a kernel that leaves the HBM idle (it is bound by per-wavefront latency
 // chains) instead of making a 9 us clear pass at the head of every level.
-__global__ __launch_bounds__(256) void nmi_level_front_kernel(PackedCloud pc, long long npoints, const float *__restrict__ mvps, int views,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void nmi_level_front_kernel(PackedCloud pc, long long npoints, const float *__restrict__ mvps, int views,
                                                               uint32_t *__restrict__ zbuf, size_t pair_words, const uint32_t *__restrict__ epoch,
                                                               int width, int height, int size, int stride,
                                                               const uint8_t *__restrict__ frame, const float *__restrict__ coeffs,
                                                               uint8_t *__restrict__ warps, int warp_blocks, int splat_blocks, int clear_blocks)
 {
-    if ((int)blockIdx.x < warp_blocks) {
-        warp_lds_block_linear(frame, coeffs, warps, width, height, (int)blockIdx.x, (int)threadIdx.x);
+    // Order of the launch: splat blocks, warp blocks, clear blocks.  Workgroups are dispatched in order; with the 2,835 warp blocks
+    // in front (six resident per CU) the first splat block would start ~12 us into the kernel, and the splat's atomics -- which
+    // run at the memory side's rate whatever else the chip does -- would start that late.  Warp and clear blocks are arithmetic
+    // and stores that fit beside them.  (Plane of the e2e bench: 60.9 us with the warp blocks first.)
+    if ((long long)blockIdx.x >= splat_blocks && (long long)blockIdx.x < splat_blocks + warp_blocks) {
+        warp_lds_block_linear(frame, coeffs, warps, width, height, (int)(blockIdx.x - splat_blocks), (int)threadIdx.x);
         return;
     }
     const uint32_t parity = *epoch & 1u;
-    const long long b = (long long)blockIdx.x - warp_blocks;
+    const long long b = (long long)blockIdx.x < splat_blocks ? (long long)blockIdx.x : (long long)blockIdx.x - warp_blocks;
     if (b < splat_blocks) {
         // First one test for ALL the views: the wavefront's box against six planes that hold every view's frustum (24 floats
         // behind the matrices, made by the host for this replay -- level_views_bound).  A map is mostly elsewhere -- 8 of 9

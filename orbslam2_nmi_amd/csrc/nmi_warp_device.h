@@ -65,7 +65,11 @@ __device__ __forceinline__ uint32_t warp_pixel_global(const uint8_t *__restrict_
 // which the LDS serves as a broadcast.  Arithmetic and its order are exactly nmi_warp_kernel's (the same fp32 twin
 // tests both).  Blocks whose patch exceeds the LDS budget, whose corners are not finite or whose homogeneous
 // coordinate is not positive at every corner take the global-tap form wholesale.
-constexpr int kWarpPatchBytes = 24 * 1024;
+// 16 KiB, not more: a kernel's LDS is reserved for EVERY workgroup of a launch, also for the splat / triangle workgroups that ride
+// in the same launch and never touch it, and with 24 KiB a CU held 6 workgroups instead of the 8 its wave slots allow -- five of
+// them the long-lived splat workgroups waiting on their atomics, one left for everything else (front kernel of the e2e bench's
+// level: 59.1 -> 56.7 us with 8).  The grid's rotations need ~7 KiB; a larger patch takes the global-tap form.
+constexpr int kWarpPatchBytes = 16 * 1024 - 64;
 constexpr int kWarpRowsPerThread = 4;  // a block covers 128 x 32 output pixels: one patch fetch per 4096 pixels
 
 // One block of 256 lanes (tx = 0..31, ty = 0..7) = 128 x 32 output pixels of warp wi: block column bx, block row by.
