@@ -228,7 +228,8 @@ int nmi_sort_triangles(nmi_ctx *ctx, const float *d_xyz /*[3*T][3]*/, const floa
 /*
  * One whole search level on the device as a captured HIP graph: S renders of the cloud (nmi_render_points), Wn warps of the
  * frame (nmi_warp_stack) and the S x Wn search (nmi_search_grid) replay with a single hipGraphLaunch -- one chain of four
- * kernel nodes (parameter fetch + clear; warp stack + splat in one launch; resolve; search), no copy nodes, no branches.
+ * kernel nodes (parameter fetch + a cull of the cloud's 64-point boxes against the planes around all views; warp stack + splat of
+ * the surviving points in one launch; resolve; search), no copy nodes, no branches.
  * Create once per (cloud, frame, S, Wn); nmi_level_run takes this level's S view matrices (nmi_render_mvp, float[S][16]) and
  * Wn forward homographies (nmi_warp_homographies, double[Wn][9]) and blocks until the search has posted its winner to pinned
  * host memory (the context's stream drains a few microseconds later; work enqueued on it afterwards is ordered as usual).

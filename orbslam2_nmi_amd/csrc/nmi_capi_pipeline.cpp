@@ -8,12 +8,16 @@ extern "C" {
 
 // ---------------------------------------------------------------------------------------------------------
 // One search level as a captured HIP graph: cloud -> S renders, frame -> Wn warps, grid search, winner to the host.
-// Five kernel nodes and no copy nodes replay with one hipGraphLaunch:
-//   prep (reads the pinned parameter buffers, resets the key, clears the anchor buffer)
-//     -> splat -> resolve  \
-//     -> warp (forked branch: it only needs the frame and its coefficients, and hides behind the VALU-bound splat)
-//                           -> search, whose last workgroup stores the winner into pinned host memory.
-// Only the pinned parameter buffers change between replays; the caller polls the winner word.
+// One chain of kernel nodes and no copy nodes replays with one hipGraphLaunch (point cloud):
+//   prep    reads the pinned parameter buffers, resets the key, bumps the replay parity; its other workgroups test the cloud's
+//           64-point boxes -- a lane per box -- against the six planes around all views and list the survivors
+//   front   a bounded number of splat workgroups over that list + the warp stack's workgroups + the clear of the NEXT replay's
+//           anchor buffer
+//   resolve sprites from anchors
+//   search  whose last workgroup stores the winner into pinned host memory.
+// (Textured mesh: prep -> binning + warp workgroups -> clip -> tiles -> search.  Where the warp cannot ride along -- frame rows
+// not 16-byte aligned -- it runs on a forked branch.)  Only the pinned parameter buffers change between replays; the caller
+// polls the winner word.
 // ---------------------------------------------------------------------------------------------------------
 }  // extern "C"
 
@@ -27,6 +31,8 @@ struct nmi_level {
     nmi::MeshWork mesh;                         // textured mesh: the renderer's work area (kept clean by the renderer itself)
     bool is_mesh = false;
     bool fused_points = false;                  // point cloud, one chain of kernels, double-buffered anchors
+    uint32_t *d_kept = nullptr, *d_kept_count = nullptr;  // ... and the wavefronts in reach of a view, listed by the prep kernel per replay
+    uint32_t replay = 0;                        // parity of the counters the prep kernel counts under
     float *d_mvps = nullptr, *h_mvps = nullptr, *d_coeffs = nullptr, *h_coeffs = nullptr;
     int *d_order = nullptr;
     float *d_ratings = nullptr;                 // [Wn][S] rating table of the latest replay
@@ -48,7 +54,7 @@ int nmi_level_destroy(nmi_level *lv)
     (void)hipStreamSynchronize(lv->ctx->stream);
     if (lv->exec) (void)hipGraphExecDestroy(lv->exec);
     if (lv->graph) (void)hipGraphDestroy(lv->graph);
-    void *dev[] = {lv->d_packed, lv->d_renders, lv->d_warps, lv->d_zbuf, lv->d_mvps, lv->d_coeffs, lv->d_order, lv->d_key, lv->d_done, lv->d_ratings, lv->d_epoch};
+    void *dev[] = {lv->d_kept, lv->d_kept_count, lv->d_packed, lv->d_renders, lv->d_warps, lv->d_zbuf, lv->d_mvps, lv->d_coeffs, lv->d_order, lv->d_key, lv->d_done, lv->d_ratings, lv->d_epoch};
     for (void *q : dev)
         if (q) (void)hipFree(q);
     void *host[] = {lv->h_mvps, lv->h_coeffs, lv->h_key};
@@ -135,6 +141,11 @@ static int level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_attr, i
         if (e == hipSuccess) ok(hipMemsetAsync(lv->d_zbuf, 0xFF, words * sizeof(uint32_t), ctx->stream));
         if (e == hipSuccess) ok(hipMemsetAsync(lv->d_epoch, 0, sizeof(uint32_t), ctx->stream));
         if (e == hipSuccess) ok(nmi::launch_cloud_pack(d_xyz, d_red, n_points, lv->d_packed, ctx->stream));
+        if (lv->fused_points) {
+            ok(hipMalloc((void **)&lv->d_kept, (size_t)(2 * ((n_points + 63) / 64) + 1) * sizeof(uint32_t)));   // (twice the most one replay lists)
+            ok(hipMalloc((void **)&lv->d_kept_count, 2 * sizeof(uint32_t)));
+            if (e == hipSuccess) ok(hipMemsetAsync(lv->d_kept_count, 0, 2 * sizeof(uint32_t), ctx->stream));
+        }
     }
     ok(hipMalloc((void **)&lv->d_mvps, ((size_t)S * 16 + nmi::kLevelMvpExtra) * sizeof(float)));
     ok(hipMalloc((void **)&lv->d_coeffs, (size_t)Wn * 9 * sizeof(float)));
@@ -198,7 +209,8 @@ static int level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_attr, i
         // (mesh: nothing to clear -- the renderer leaves its work area clean)
         ok(nmi::launch_level_prep(hd_mvps, lv->d_mvps, S * 16 + nmi::kLevelMvpExtra, hd_coeffs, lv->d_coeffs, Wn * 9, lv->d_key, lv->d_zbuf,
                                   (tex || lv->fused_points) ? 0 : nmi::render_zbuf_words(S, p.width, p.height, lv->size), st,
-                                  lv->fused_points ? lv->d_epoch : nullptr));
+                                  lv->fused_points ? lv->d_epoch : nullptr, lv->fused_points ? lv->d_packed : nullptr, n_points,
+                                  lv->fused_points ? hd_mvps + (size_t)S * 16 : nullptr, lv->d_kept, lv->d_kept_count));
         // One chain of kernels when the warp blocks can ride along with the render's first kernel (the usual case: frame rows
         // 16-byte aligned); otherwise the warp kernel runs on a forked branch beside the render.
         const bool fused = tex ? (nmi::level_front_eligible(d_frame, lv->d_warps, p.width, S) && n_points > 0) : lv->fused_points;
@@ -214,7 +226,7 @@ static int level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_attr, i
                                        p.width, p.height, st, fused ? d_frame : nullptr, lv->d_coeffs, lv->d_warps, Wn));
         else if (fused)
             ok(nmi::launch_level_front_points(lv->d_packed, n_points, lv->d_mvps, S, lv->d_zbuf, lv->d_epoch, lv->d_renders, p.width, p.height,
-                                              lv->size, d_frame, lv->d_coeffs, lv->d_warps, Wn, st));
+                                              lv->size, d_frame, lv->d_coeffs, lv->d_warps, Wn, st, lv->d_kept, lv->d_kept_count, ctx->compute_units));
         else
             ok(nmi::launch_render_points(d_xyz, d_red, n_points, lv->d_mvps, S, lv->d_zbuf, lv->d_renders, p.width, p.height, lv->size, st,
                                          /*clear_first=*/false));
@@ -275,7 +287,9 @@ static int level_launch(nmi_level *lv, const float *h_mvps, const double *h_forw
     memcpy(lv->h_mvps, h_mvps, (size_t)lv->S * 16 * sizeof(float));
     nmi::level_views_bound(h_mvps, lv->S, lv->h_mvps + (size_t)lv->S * 16);  // for the front kernel's first test: all views at once
     static const bool no_bound = getenv("NMI_LEVEL_NO_BOUND") != nullptr;      // measurement switch: six zero planes cull nothing
-    if (no_bound) memset(lv->h_mvps + (size_t)lv->S * 16, 0, nmi::kLevelMvpExtra * sizeof(float));
+    if (no_bound) memset(lv->h_mvps + (size_t)lv->S * 16, 0, 24 * sizeof(float));
+    const uint32_t parity = ++lv->replay & 1u;  // which of its two counters the prep kernel's cull counts under (it zeroes the other one)
+    memcpy(lv->h_mvps + (size_t)lv->S * 16 + 24, &parity, sizeof parity);
     for (int w = 0; w < lv->Wn; ++w) {
         const double *m = h_forward + (size_t)w * 9;
         const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
@@ -287,7 +301,11 @@ static int level_launch(nmi_level *lv, const float *h_mvps, const double *h_forw
     }
     constexpr unsigned long long kPending = ~0ull;
     __atomic_store_n(lv->h_key, kPending, __ATOMIC_RELEASE);
-    NMI_HIP_TRY(ctx, hipGraphLaunch(lv->exec, ctx->stream));
+    const hipError_t le = hipGraphLaunch(lv->exec, ctx->stream);
+    if (le != hipSuccess) {
+        --lv->replay;  // (the replay did not run: its counter has not been counted into, the other one has not been zeroed)
+        return hip_fail(ctx, le, "hipGraphLaunch");
+    }
     return NMI_OK;
 }
 

@@ -173,13 +173,17 @@ size_t cloud_pack_bytes(long long npoints, size_t *boxes_offset);
 hipError_t launch_cloud_pack(const float *xyz, const float *red, long long npoints, void *packed, hipStream_t stream);
 bool level_front_eligible(const void *frame, const void *warps, int width, int S);
 void level_views_bound(const float *mvps /*[S][16] column-major*/, int S, float out[24]);  // host: 6 planes around the S views' frusta
-constexpr int kLevelMvpExtra = 24;  // floats behind a level's S matrices: those planes
+constexpr int kLevelMvpExtra = 28;  // floats behind a level's S matrices: those planes (24), the replay's parity as a word, padding
 bool level_points_double_buffered(int width, int size);  // the fused front kernel's form of the anchors: two buffers, cleared in turn
 size_t level_zbuf_pair_words(int S, int width, int height, int size);
 hipError_t launch_level_front_points(const void *packed, long long npoints, const float *mvps, int S, uint32_t *zbuf /* two buffers */,
                                      const uint32_t *epoch, uint8_t *out, int width, int height, int size, const uint8_t *frame,
-                                     const float *coeffs, uint8_t *warps, int Wn, hipStream_t stream);
+                                     const float *coeffs, uint8_t *warps, int Wn, hipStream_t stream,
+                                     const uint32_t *kept /* [ceil(n / 64)]: wavefronts in reach of a view, made by the prep kernel */,
+                                     const uint32_t *kept_count /* [2], by replay parity */, int compute_units);
 hipError_t launch_level_prep(const float *h_mvps, float *d_mvps, int n_mvps, const float *h_coeffs, float *d_coeffs, int n_coeffs,
-                             unsigned long long *key, uint32_t *zbuf, size_t nz, hipStream_t stream, uint32_t *epoch = nullptr);
+                             unsigned long long *key, uint32_t *zbuf, size_t nz, hipStream_t stream, uint32_t *epoch = nullptr,
+                             const void *packed = nullptr, long long npoints = 0, const float *h_bound /* pinned: 24 floats + parity word */ = nullptr,
+                             uint32_t *kept = nullptr, uint32_t *kept_count = nullptr);
 
 }  // namespace nmi

@@ -120,12 +120,34 @@ __global__ __launch_bounds__(256) void nmi_zbuf_clear_kernel(uint32_t *zbuf, siz
 // First node of a captured search level (nmi_level_*): what would otherwise be two parameter uploads, a key reset
 // and the buffer clear -- four graph nodes with a hand-over each -- as one kernel.  The parameters are read straight
 // from the caller's pinned (device-mapped) buffers.
+// With `kept` (a point-cloud level's fused form) the launch has more workgroups: workgroup b >= 1 tests the boxes of wavefronts
+// 256 (b - 1) .. of the packed cloud -- ONE LANE PER BOX -- against the six planes around all the views (read straight from the
+// host's pinned buffer: `h_bound` = 24 floats + the replay's parity word) and appends the numbers of those that any view may
+// see to the compact list kept[], one counter update per wavefront.  The front kernel then runs a bounded number of worker
+// workgroups over that list instead of one wavefront per 64 points of the whole map.  Two counters, used in turn (parity):
+// workgroup 0 zeroes the one the NEXT replay will count into.
 __global__ __launch_bounds__(256) void nmi_level_prep_kernel(const float *__restrict__ h_mvps, float *__restrict__ d_mvps, int n_mvps,
                                                              const float *__restrict__ h_coeffs, float *__restrict__ d_coeffs, int n_coeffs,
-                                                             unsigned long long *key, uint32_t *zbuf, size_t nz, uint32_t *epoch)
+                                                             unsigned long long *key, uint32_t *zbuf, size_t nz, uint32_t *epoch,
+                                                             const float4 *__restrict__ boxes, long long nwaves, const float *__restrict__ h_bound,
+                                                             uint32_t *__restrict__ kept, uint32_t *__restrict__ kept_count)
 {
+    if (kept && blockIdx.x > 0) {
+        const uint32_t parity = __float_as_uint(h_bound[24]) & 1u;   // (wavefront-uniform addresses in host memory: scalar loads, one PCIe trip)
+        const long long w = ((long long)blockIdx.x - 1) * 256 + threadIdx.x;
+        bool in = false;
+        if (w < nwaves) in = !box_outside_bound(h_bound, boxes[2 * w], boxes[2 * w + 1]);
+        const unsigned long long mask = __ballot(in);
+        const int lane = (int)(threadIdx.x & 63);
+        uint32_t base = 0;
+        if (lane == 0 && mask) base = atomicAdd(&kept_count[parity], (uint32_t)__popcll(mask));
+        base = (uint32_t)__shfl((int)base, 0, 64);
+        if (in) kept[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)w;
+        return;
+    }
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
     if (blockIdx.x == 0) {
+        if (kept && threadIdx.x == 64) kept_count[(__float_as_uint(h_bound[24]) & 1u) ^ 1u] = 0u;
         // Every read of the host's buffers is a round trip over PCIe (about 2 us): all of them are asked for before the first
         // one is used, so the kernel costs one round trip, not one per loop iteration (7 us -> 4 us on the level's serial path).
         const int bd = (int)blockDim.x, i0 = (int)threadIdx.x;
@@ -153,10 +175,21 @@ __global__ __launch_bounds__(256) void nmi_level_prep_kernel(const float *__rest
 }
 
 hipError_t launch_level_prep(const float *h_mvps, float *d_mvps, int n_mvps, const float *h_coeffs, float *d_coeffs, int n_coeffs,
-                             unsigned long long *key, uint32_t *zbuf, size_t nz, hipStream_t stream, uint32_t *epoch)
+                             unsigned long long *key, uint32_t *zbuf, size_t nz, hipStream_t stream, uint32_t *epoch, const void *packed,
+                             long long npoints, const float *h_bound, uint32_t *kept, uint32_t *kept_count)
 {
-    hipLaunchKernelGGL(nmi_level_prep_kernel, dim3(nz ? 2048 : 1), dim3(256), 0, stream, h_mvps, d_mvps, n_mvps, h_coeffs, d_coeffs, n_coeffs, key,
-                       zbuf, nz, epoch);
+    const float4 *boxes = nullptr;
+    long long nwaves = 0;
+    if (kept) {
+        if (nz || !packed || !h_bound || !kept_count) return hipErrorInvalidValue;
+        size_t off = 0;
+        (void)cloud_pack_bytes(npoints, &off);
+        boxes = reinterpret_cast<const float4 *>(static_cast<const char *>(packed) + off);
+        nwaves = (npoints + 63) / 64;
+    }
+    const unsigned blocks = kept ? 1u + (unsigned)((nwaves + 255) / 256) : (nz ? 2048u : 1u);
+    hipLaunchKernelGGL(nmi_level_prep_kernel, dim3(blocks), dim3(256), 0, stream, h_mvps, d_mvps, n_mvps, h_coeffs, d_coeffs, n_coeffs, key, zbuf, nz,
+                       epoch, boxes, nwaves, h_bound, kept, kept_count);
     return hipGetLastError();
 }
 
@@ -282,12 +315,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                               uint32_t *__restrict__ zbuf, size_t pair_words, const uint32_t *__restrict__ epoch,
                                                               int width, int height, int size, int stride,
                                                               const uint8_t *__restrict__ frame, const float *__restrict__ coeffs,
-                                                              uint8_t *__restrict__ warps, int warp_blocks, int splat_blocks, int clear_blocks)
+                                                              uint8_t *__restrict__ warps, int warp_blocks, int splat_blocks, int clear_blocks,
+                                                              const uint32_t *__restrict__ kept, const uint32_t *__restrict__ kept_count)
 {
-    // Order of the launch: splat blocks, warp blocks, clear blocks.  Workgroups are dispatched in order; with the 2,835 warp blocks
-    // in front (six resident per CU) the first splat block would start ~12 us into the kernel, and the splat's atomics -- which
-    // run at the memory side's rate whatever else the chip does -- would start that late.  Warp and clear blocks are arithmetic
-    // and stores that fit beside them.  (Plane of the e2e bench: 60.9 us with the warp blocks first.)
+    // Order of the launch: splat workers, warp blocks, clear blocks.  The splat's atomics run at the memory side's rate whatever
+    // else the chip does, so they start at once; warp and clear blocks are arithmetic and stores that fit beside them.
+    // The splat workers are a BOUNDED number of workgroups (launch_level_front_points: three per CU) that share out the list of
+    // wavefronts the prep kernel found in reach of a view: a wavefront of the splat spends its life waiting for its turn at the
+    // CU's atomic path, and one per 64 visible points -- 20 per CU on the benchmark's cloud -- held the CU's wave slots while the
+    // warp blocks queued (plane of the e2e bench: splat alone 41 us, warp alone 25, together 57; and the 8 of 9 wavefronts
+    // that see nothing no longer exist as wavefronts at all).
     if ((long long)blockIdx.x >= splat_blocks && (long long)blockIdx.x < splat_blocks + warp_blocks) {
         warp_lds_block_linear(frame, coeffs, warps, width, height, (int)(blockIdx.x - splat_blocks), (int)threadIdx.x);
         return;
@@ -295,17 +332,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const uint32_t parity = *epoch & 1u;
     const long long b = (long long)blockIdx.x < splat_blocks ? (long long)blockIdx.x : (long long)blockIdx.x - warp_blocks;
     if (b < splat_blocks) {
-        // First one test for ALL the views: the wavefront's box against six planes that hold every view's frustum (24 floats
-        // behind the matrices, made by the host for this replay -- level_views_bound).  A map is mostly elsewhere -- 8 of 9
-        // wavefronts of the benchmark's cloud -- and those neither fetch their points nor run the per-view plane tests.
-        const long long wave = (b * 256 + threadIdx.x) >> 6;
-        if (wave * 64 < npoints) {
-            const float4 lo = pc.boxes[2 * wave], hi = pc.boxes[2 * wave + 1];
-            const bool out = box_outside_bound(mvps + (size_t)views * 16, lo, hi);
-            if (out) return;  // wavefront-uniform
+        const uint32_t n = kept_count[__float_as_uint(mvps[(size_t)views * 16 + 24]) & 1u];   // (the parity the prep kernel counted under)
+        const uint32_t first = (uint32_t)b * 4u + (threadIdx.x >> 6), step = (uint32_t)splat_blocks * 4u;
+        for (uint32_t e = first; e < n; e += step) {
+            const long long wave = (long long)__builtin_amdgcn_readfirstlane((int)kept[e]);
+            splat_wave<true>(nullptr, nullptr, pc, npoints, mvps, views, zbuf + (size_t)parity * pair_words, width, height, size, stride, wave,
+                             (int)(threadIdx.x & 63));
         }
-        splat_wave<true>(nullptr, nullptr, pc, npoints, mvps, views, zbuf + (size_t)parity * pair_words, width, height, size, stride, wave,
-                         (int)(threadIdx.x & 63));
         return;
     }
     uint4 *other = reinterpret_cast<uint4 *>(zbuf + (size_t)(parity ^ 1u) * pair_words);  // (pair_words is a multiple of 4)
@@ -471,15 +504,19 @@ size_t level_zbuf_pair_words(int S, int width, int height, int size) { return (r
 // non-negative side (level_views_bound; all zero switches the test off).  S <= 64 views.
 hipError_t launch_level_front_points(const void *packed, long long npoints, const float *mvps, int S, uint32_t *zbuf, const uint32_t *epoch,
                                      uint8_t *out, int width, int height, int size, const uint8_t *frame, const float *coeffs, uint8_t *warps,
-                                     int Wn, hipStream_t stream)
+                                     int Wn, hipStream_t stream, const uint32_t *kept, const uint32_t *kept_count, int compute_units)
 {
-    if (S > kMaxViewsPerLaunch || !warp_lds_eligible(frame, warps, width)) return hipErrorInvalidValue;
+    if (S > kMaxViewsPerLaunch || !warp_lds_eligible(frame, warps, width) || !kept || !kept_count) return hipErrorInvalidValue;
     if (!((width & 3) == 0 && size <= 5 && (((uintptr_t)zbuf & 15) == 0) && (((uintptr_t)out & 3) == 0))) return hipErrorInvalidValue;
     size_t off = 0;
     (void)cloud_pack_bytes(npoints, &off);
     PackedCloud pc{reinterpret_cast<const float4 *>(packed), reinterpret_cast<const float4 *>(static_cast<const char *>(packed) + off)};
     int warp_blocks = warp_blocks_x(width) * warp_blocks_y(height) * Wn;
-    long long splat_blocks = (npoints + 255) / 256;
+    // splat workers: three workgroups (12 wavefronts) per CU keep the CU's atomic path busy and leave five workgroup slots to the
+    // warp blocks; never more than one wavefront per 64 points
+    static const int per_cu = getenv("NMI_FRONT_WORKERS") ? atoi(getenv("NMI_FRONT_WORKERS")) : 3;
+    long long splat_blocks = (long long)(compute_units > 0 ? compute_units : 256) * (per_cu > 0 ? per_cu : 3);
+    if (splat_blocks > (npoints + 255) / 256) splat_blocks = (npoints + 255) / 256;
     const int stride = zbuf_stride(width, size);
     const size_t pair_words = level_zbuf_pair_words(S, width, height, size);
     static const int dbg = getenv("NMI_FRONT_DBG") ? atoi(getenv("NMI_FRONT_DBG")) : 0;  // profiling ablations (tools only): 1 no warp blocks, 2 no splat blocks, 4 no clear blocks
@@ -487,7 +524,8 @@ hipError_t launch_level_front_points(const void *packed, long long npoints, cons
     if (dbg & 2) splat_blocks = 0, npoints = 0;
     const int clear_blocks = (dbg & 4) ? 0 : 1024;
     hipLaunchKernelGGL(nmi_level_front_kernel, dim3((unsigned)(warp_blocks + splat_blocks + clear_blocks)), dim3(256), 0, stream, pc, npoints, mvps,
-                       S, zbuf, pair_words, epoch, width, height, size, stride, frame, coeffs, warps, warp_blocks, (int)splat_blocks, clear_blocks);
+                       S, zbuf, pair_words, epoch, width, height, size, stride, frame, coeffs, warps, warp_blocks, (int)splat_blocks, clear_blocks,
+                       kept, kept_count);
     launch_resolve(zbuf, out, S, width, height, size, stream, epoch, pair_words);
     return hipGetLastError();
 }
