@@ -183,6 +183,34 @@ def test_gpu_level_graph_equals_separate_calls():
 
 
 @pytest.mark.gpu
+def test_gpu_level_without_common_planes_lists_every_wavefront():
+    """One view matrix that cannot be inverted: the host finds no planes around the views (six zero planes), the prep kernel then
+    lists EVERY wavefront of the cloud for the front kernel's workers, and the renders are still nmi_render_points' -- the
+    unusable view included (all its points are clipped either way)."""
+    torch = pytest.importorskip("torch")
+    import orbslam2_nmi_amd as nmi
+    w, h, S, Wn = 160, 120, 4, 1
+    rng = np.random.default_rng(5)
+    K = sy.intrinsics(w, h)
+    rp = capi.RenderParams(fx=K[0, 0], fy=K[1, 1], cx=K[0, 2], cy=K[1, 2], near_plane=0.5, far_plane=40.0, point_size=2.0)
+    n = 70_001   # (not a multiple of 64: the last wavefront is ragged)
+    xyz = (rng.uniform(-1, 1, (n, 3)) * [12, 9, 12] + [0, 0, 8]).astype(np.float32)
+    red = rng.uniform(0, 1, n).astype(np.float32)
+    mvps = np.stack([capi.render_mvp(rp, (0.1 * s, 0, 0), (0.1 * s, 0.05 * s, 1), (0, -1, 0), (0, 0, 0)) for s in range(S)])
+    mvps[2] = 0.0
+    Ms = capi.warp_homographies(K, (Wn, 1, 1), (0.02, 0.02, 0.05))
+    with nmi.NmiContext(w, h) as ctx:
+        dx, dr = torch.from_numpy(xyz).cuda(), torch.from_numpy(red).cuda()
+        frame = ctx.render_points(dx, dr, mvps[:1], 2.0)[0].contiguous()
+        want = ctx.render_points(dx, dr, mvps, 2.0).cpu().numpy()
+        assert (want[2] == 255).all() and (want[0] != 255).any()
+        with nmi.NmiLevel(ctx, dx, dr, frame, S, Wn, 2.0) as lv:
+            for rep in range(3):
+                lv.run(mvps, Ms)
+                assert np.array_equal(lv.outputs()[0], want), rep
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", [11, 12, 13])
 def test_gpu_level_cull_by_common_planes_changes_nothing(seed):
     """A level's front kernel first tests a wavefront's box against six planes around ALL the views' frusta (made by the host per
