@@ -1,7 +1,11 @@
+"""One-off wider campaign of tests/test_render.py::test_gpu_level_cull_by_common_planes_changes_nothing: N more seeds (100..).
+    python3 tools/campaign_level_cull.py 40
+Round 3: 40 + 20 + 20 seeds, no failure."""
 import sys, os, time
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(sys.path[0], "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import importlib.util
-spec = importlib.util.spec_from_file_location("test_render", os.path.join(sys.path[0], "test_render.py"))
+spec = importlib.util.spec_from_file_location("test_render", os.path.join(ROOT, "tests", "test_render.py"))
 m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
 bad = []
 for seed in range(100, 100 + int(sys.argv[1])):
