@@ -129,6 +129,7 @@ static int level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_attr, i
     lv->is_mesh = tex != nullptr;
     if (tex) {
         if (mesh_work_alloc(ctx, S, &lv->mesh) != NMI_OK) e = hipErrorOutOfMemory;
+        if (e == hipSuccess && ensure_mesh_pairs(ctx, &lv->mesh, n_points) != NMI_OK) e = hipErrorOutOfMemory;
     } else {
         // Anchors: two buffers when the level runs as one chain of kernels (the front kernel of replay k clears the buffer of
         // replay k + 1); the classic form keeps one and clears it in its prep node.

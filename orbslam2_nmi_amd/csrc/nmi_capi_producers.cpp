@@ -18,13 +18,35 @@ int mesh_work_alloc(nmi_ctx *ctx, int S, nmi::MeshWork *w)
     NMI_HIP_TRY(ctx, hipMalloc(&w->clip_queue, (size_t)kClipItems * nmi::mesh_clip_item_bytes()));
     w->clip_cap = kClipItems;
     NMI_HIP_TRY(ctx, hipMalloc((void **)&w->clip_state, 2 * sizeof(unsigned long long)));
+    NMI_HIP_TRY(ctx, hipMalloc((void **)&w->pair_state, sizeof(uint32_t)));
+    NMI_HIP_TRY(ctx, hipMemsetAsync(w->pair_state, 0, sizeof(uint32_t), ctx->stream));
+    w->compute_units = ctx->compute_units;
     NMI_HIP_TRY(ctx, nmi::launch_mesh_clear(*w, S, width, height, ctx->stream));
+    return NMI_OK;
+}
+
+// The pair list of the two-kernel binning pass: 64 entries per block of 256 triangles (grown on demand; a level sizes it once).
+int ensure_mesh_pairs(nmi_ctx *ctx, nmi::MeshWork *w, long long n_triangles)
+{
+    const unsigned long long need = nmi::mesh_pairs_entries(n_triangles);
+    if (need <= w->pairs_cap) return NMI_OK;
+    if (w->pairs) {
+        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(w->pairs);
+        w->pairs = nullptr, w->pairs_cap = 0;
+    }
+    if (hipMalloc((void **)&w->pairs, (size_t)need * sizeof(uint32_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        w->pairs = nullptr;   // (no list: launch_render_mesh takes the one-kernel form)
+        return NMI_OK;
+    }
+    w->pairs_cap = need;
     return NMI_OK;
 }
 
 void mesh_work_free(nmi::MeshWork *w)
 {
-    void *all[] = {w->zbuf, w->bins, w->state, w->clip_queue, w->clip_state};
+    void *all[] = {w->zbuf, w->bins, w->state, w->clip_queue, w->clip_state, w->pairs, w->pair_state};
     for (void *q : all)
         if (q) (void)hipFree(q);
     *w = nmi::MeshWork{};
@@ -276,6 +298,7 @@ int nmi_render_mesh(nmi_ctx *ctx, const float *d_xyz, const float *d_uv, int64_t
     // laid out for that many views; the first S of them are used)
     int rq = ensure_mesh_work(ctx, S);
     if (rq != NMI_OK) return rq;
+    if ((rq = ensure_mesh_pairs(ctx, &ctx->mesh, n_triangles)) != NMI_OK) return rq;
     float *d_mvps = nullptr;
     int rc = stage_floats(ctx, ctx->mvp_ring, h_mvps, (size_t)S * 16, &d_mvps);
     if (rc != NMI_OK) return rc;

@@ -139,6 +139,7 @@ namespace nmi_internal {
 int mesh_work_alloc(nmi_ctx *ctx, int S, nmi::MeshWork *w);
 void mesh_work_free(nmi::MeshWork *w);
 int ensure_mesh_work(nmi_ctx *ctx, int S);  // the context's own, grown on demand
+int ensure_mesh_pairs(nmi_ctx *ctx, nmi::MeshWork *w, long long n_triangles);  // the pair list of the two-kernel binning pass
 int level_enqueue(nmi_level *lv, const float *h_mvps, const double *h_forward, const unsigned long long **d_key);
 nmi_ctx *level_ctx(nmi_level *lv);
 // ncclAllReduce(ncclMax, ncclUint64) of one 8-byte key on the context's stream, out of place (nmi_capi_rccl.cpp)

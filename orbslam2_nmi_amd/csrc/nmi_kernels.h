@@ -143,7 +143,12 @@ struct MeshWork {
     void *clip_queue = nullptr;                // (triangle, view) pairs that cross the near plane
     unsigned long long clip_cap = 0;
     unsigned long long *clip_state = nullptr;  // [2]
+    uint32_t *pairs = nullptr;                 // optional: (block of 256 triangles, view) pairs in reach of each other, listed per render
+    uint32_t *pair_state = nullptr;            //   [1] entries listed (zero between renders)
+    unsigned long long pairs_cap = 0;          //   entries `pairs` holds; the two-kernel binning pass needs 64 per block of the mesh
+    int compute_units = 0;
 };
+size_t mesh_pairs_entries(long long ntri);     // what pairs_cap must be for a mesh of ntri triangles
 size_t mesh_zbuf_bytes(int S, int width, int height);
 size_t mesh_bins_bytes(int S, int width, int height);
 size_t mesh_state_bytes(int S, int width, int height);

@@ -495,6 +495,60 @@ __device__ __forceinline__ int bin_commit(const BinGrid &g, int want, uint32_t i
 
 }  // namespace
 
+// One triangle per lane (tri, corners px/py/pz; `valid` false: the lane only takes part in the wavefront's appends) through view s
+// (matrix m, 16 floats in any address space): a small pixel box is rasterised right here, a large one goes to the bins of the tiles
+// it touches, one that crosses the near plane to the clip queue.  Wavefront-level code: no barrier, no LDS.
+template <typename M>
+__device__ __forceinline__ void bin_one_view(const M *m, int s, long long tri, bool valid, const float (&px)[3], const float (&py)[3],
+                                             const float (&pz)[3], int width, int height, const BinGrid &g, ClipItem *__restrict__ clipq,
+                                             unsigned long long *__restrict__ clip_state, unsigned long long clip_cap)
+{
+    const int tiles = g.tiles_x * g.tiles_y;
+        TriView t;
+        bool large = false;
+        if (valid) {
+            float cx[3], cy[3], cz[3], cw[3], d[3];
+            const int n_in = tri_clip_coords(m, px, py, pz, cx, cy, cz, cw, d);
+            if (n_in == 3) {
+                if (tri_setup(cx, cy, cz, cw, width, height, t)) {
+                    const int bw = t.x_hi - t.x_lo + 1, bh = t.y_hi - t.y_lo + 1;
+                    large = bw * bh > kSmallBox && g.cap > 0 && !(g.dbg & 256);
+                    if (!large && !(g.dbg & 256)) raster_direct(t, t.x_lo, t.x_hi, t.y_lo, t.y_hi, (unsigned long long)tri << 1, g, s, width, height);
+                }
+            } else if (n_in > 0) {  // crosses the near plane: nmi_mesh_clip_kernel's business
+                const unsigned long long at = atomicAdd(&clip_state[0], 1ull);
+                if (at < clip_cap) clipq[at] = ClipItem{(unsigned long long)tri, (uint32_t)s, 0u};
+            }
+        }
+        // large triangles: one bin entry per tile their box touches.  All lanes of the wavefront walk their tiles together, four
+        // tile steps to a batch: the batch's counter updates are in flight together (bin_reserve), then its entries are stored.
+        const int tx0 = large ? t.x_lo / kTile : 0, tx1 = large ? t.x_hi / kTile : -1, ty0 = large ? t.y_lo / kTile : 0, ty1 = large ? t.y_hi / kTile : -1;
+        int cxt = tx0, cyt = ty0;
+        bool more = large;
+        while (__any(more)) {
+            constexpr int kBatch = 4;
+            int want[kBatch], at_x[kBatch], at_y[kBatch];
+            BinTicket ticket[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                want[u] = more ? s * tiles + cyt * g.tiles_x + cxt : -1;
+                at_x[u] = cxt, at_y[u] = cyt;
+                ticket[u] = bin_reserve(g, want[u]);
+                if (more && ++cxt > tx1) {
+                    cxt = tx0;
+                    if (++cyt > ty1) more = false;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                const int slot = bin_commit(g, want[u], (uint32_t)(tri << 1), ticket[u]);
+                if (want[u] >= 0 && slot < 0)  // bin full: this lane rasterises its triangle's part of the tile itself
+                    raster_direct(t, max(t.x_lo, at_x[u] * kTile), min(t.x_hi, at_x[u] * kTile + kTile - 1), max(t.y_lo, at_y[u] * kTile),
+                                  min(t.y_hi, at_y[u] * kTile + kTile - 1), (unsigned long long)tri << 1, g, s, width, height);
+            }
+        }
+}
+
 // (A captured level passes its warp stack's work along: the first wf.blocks workgroups of the launch are warp blocks,
 // nmi_warp_device.h, and the graph needs no branch for them.)
 struct WarpFuse {
@@ -544,53 +598,73 @@ __global__ __launch_bounds__(256) void nmi_mesh_bin_kernel(const float *__restri
                              valid ? fmaxf(pz[0], fmaxf(pz[1], pz[2])) : -inf};
         block_frustum_cull(m_all, v_first, v_end, lo, hi, wave_box, beyond);
     }
-    const int tiles = g.tiles_x * g.tiles_y;
     if (g.dbg & 128) return;
     for (int s = v_first; s < v_end; ++s) {
         if (beyond[s]) continue;  // block-uniform
-        TriView t;
-        bool large = false;
-        if (valid) {
-            float cx[3], cy[3], cz[3], cw[3], d[3];
-            const int n_in = tri_clip_coords(m_all + s * 16, px, py, pz, cx, cy, cz, cw, d);
-            if (n_in == 3) {
-                if (tri_setup(cx, cy, cz, cw, width, height, t)) {
-                    const int bw = t.x_hi - t.x_lo + 1, bh = t.y_hi - t.y_lo + 1;
-                    large = bw * bh > kSmallBox && g.cap > 0 && !(g.dbg & 256);
-                    if (!large && !(g.dbg & 256)) raster_direct(t, t.x_lo, t.x_hi, t.y_lo, t.y_hi, (unsigned long long)tri << 1, g, s, width, height);
-                }
-            } else if (n_in > 0) {  // crosses the near plane: nmi_mesh_clip_kernel's business
-                const unsigned long long at = atomicAdd(&clip_state[0], 1ull);
-                if (at < clip_cap) clipq[at] = ClipItem{(unsigned long long)tri, (uint32_t)s, 0u};
-            }
-        }
-        // large triangles: one bin entry per tile their box touches.  All lanes of the wavefront walk their tiles together, four
-        // tile steps to a batch: the batch's counter updates are in flight together (bin_reserve), then its entries are stored.
-        const int tx0 = large ? t.x_lo / kTile : 0, tx1 = large ? t.x_hi / kTile : -1, ty0 = large ? t.y_lo / kTile : 0, ty1 = large ? t.y_hi / kTile : -1;
-        int cxt = tx0, cyt = ty0;
-        bool more = large;
-        while (__any(more)) {
-            constexpr int kBatch = 4;
-            int want[kBatch], at_x[kBatch], at_y[kBatch];
-            BinTicket ticket[kBatch];
+        bin_one_view(m_all + s * 16, s, tri, valid, px, py, pz, width, height, g, clipq, clip_state, clip_cap);
+    }
+}
+
+// The two-kernel form of the binning pass (launch_render_mesh takes it whenever the work area holds a pair list).
+// nmi_mesh_cull_kernel: one workgroup per 256 triangles finds the views that can see the block's box (block_frustum_cull over ALL
+// the views at once) and appends one entry per surviving (block, view) PAIR to a list.  nmi_mesh_bin_pairs_kernel: a bounded number
+// of worker workgroups share the list out; a worker fetches a pair's 256 triangles and takes them through that ONE view.
+// Why: in the one-kernel form a workgroup that sees something walks its share of the views one after the other, every view a chain
+// of set-up and append round trips, while most workgroups of the launch had nothing to do but cost their fixed latency; here every
+// unit of work is one view deep and the launch is as wide as the chip (27 views of 120 k triangles, whole stack: 159 -> 146 us).
+__global__ __launch_bounds__(256) void nmi_mesh_cull_kernel(const float *__restrict__ xyz, long long ntri, const float *__restrict__ mvps, int views,
+                                                            uint32_t *__restrict__ pairs, uint32_t *__restrict__ pair_state)
+{
+    __shared__ float m_all[kMaxViewsPerLaunch * 16];
+    __shared__ float wave_box[4][6];
+    __shared__ uint32_t beyond[kMaxViewsPerLaunch];
+    for (int t = threadIdx.x; t < views * 16; t += blockDim.x) m_all[t] = mvps[t];
+    for (int t = threadIdx.x; t < kMaxViewsPerLaunch; t += blockDim.x) beyond[t] = t < views ? 0x3Fu : 0u;
+    const long long tri = blockIdx.x * 256ll + threadIdx.x;
+    const float inf = __builtin_huge_valf();
+    float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+    if (tri < ntri) {
 #pragma unroll
-            for (int u = 0; u < kBatch; ++u) {
-                want[u] = more ? s * tiles + cyt * g.tiles_x + cxt : -1;
-                at_x[u] = cxt, at_y[u] = cyt;
-                ticket[u] = bin_reserve(g, want[u]);
-                if (more && ++cxt > tx1) {
-                    cxt = tx0;
-                    if (++cyt > ty1) more = false;
-                }
-            }
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int u = 0; u < kBatch; ++u) {
-                const int slot = bin_commit(g, want[u], (uint32_t)(tri << 1), ticket[u]);
-                if (want[u] >= 0 && slot < 0)  // bin full: this lane rasterises its triangle's part of the tile itself
-                    raster_direct(t, max(t.x_lo, at_x[u] * kTile), min(t.x_hi, at_x[u] * kTile + kTile - 1), max(t.y_lo, at_y[u] * kTile),
-                                  min(t.y_hi, at_y[u] * kTile + kTile - 1), (unsigned long long)tri << 1, g, s, width, height);
+            for (int k = 0; k < 3; ++k) {
+                const float v = xyz[(tri * 3 + c) * 3 + k];
+                lo[k] = fminf(lo[k], v), hi[k] = fmaxf(hi[k], v);
             }
-        }
+    }
+    block_frustum_cull(m_all, 0, views, lo, hi, wave_box, beyond);
+    if (threadIdx.x < 64) {   // wavefront 0: lane s speaks for view s
+        const int lane = (int)threadIdx.x;
+        const bool alive = lane < views && beyond[lane] == 0u;
+        const unsigned long long mask = __ballot(alive);
+        uint32_t base = 0;
+        if (lane == 0 && mask) base = atomicAdd(&pair_state[0], (uint32_t)__popcll(mask));
+        base = (uint32_t)__shfl((int)base, 0, 64);
+        if (alive) pairs[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)blockIdx.x * (uint32_t)kMaxViewsPerLaunch + (uint32_t)lane;
+    }
+}
+
+__global__ __launch_bounds__(256) void nmi_mesh_bin_pairs_kernel(const float *__restrict__ xyz, const float *__restrict__ uv, long long ntri,
+                                                                 const float *__restrict__ mvps, int width, int height, BinGrid g,
+                                                                 ClipItem *__restrict__ clipq, unsigned long long *__restrict__ clip_state,
+                                                                 unsigned long long clip_cap, WarpFuse wf, const uint32_t *__restrict__ pairs,
+                                                                 const uint32_t *__restrict__ pair_state)
+{
+    const unsigned workers = gridDim.x - (unsigned)wf.blocks;   // (workers first in the launch: their round trips start at once)
+    if (blockIdx.x >= workers) {
+        warp_lds_block_linear(wf.frame, wf.coeffs, wf.warps, width, height, (int)(blockIdx.x - workers), (int)threadIdx.x);
+        return;
+    }
+    const uint32_t n = pair_state[0];
+    if (g.dbg & 128) return;
+    for (uint32_t p = blockIdx.x; p < n; p += workers) {
+        const uint32_t pair = pairs[p];
+        const int s = (int)(pair % (uint32_t)kMaxViewsPerLaunch);
+        const long long tri = (long long)(pair / (uint32_t)kMaxViewsPerLaunch) * 256ll + threadIdx.x;
+        const bool valid = tri < ntri;
+        float px[3] = {0, 0, 0}, py[3] = {0, 0, 0}, pz[3] = {0, 0, 0}, tu[3], tv[3];
+        if (valid) load_tri(xyz, uv, tri, px, py, pz, tu, tv);
+        bin_one_view(mvps + (size_t)s * 16, s, tri, valid, px, py, pz, width, height, g, clipq, clip_state, clip_cap);   // (uniform address: the matrix in scalar registers)
     }
 }
 
@@ -632,9 +706,10 @@ __device__ __forceinline__ void clip_and_bin(const float *__restrict__ xyz, cons
 __global__ __launch_bounds__(256) void nmi_mesh_clip_kernel(const float *__restrict__ xyz, const float *__restrict__ uv, long long ntri,
                                                             const float *__restrict__ mvps, int views, int width, int height, BinGrid g,
                                                             const ClipItem *__restrict__ clipq, unsigned long long *__restrict__ clip_state,
-                                                            unsigned long long clip_cap)
+                                                            unsigned long long clip_cap, uint32_t *__restrict__ pair_state)
 {
     __shared__ unsigned long long claimed_s;
+    if (pair_state && blockIdx.x == 0 && threadIdx.x == 0) pair_state[0] = 0u;   // the binning pass that read the list has ended: clean for the next render
     if (threadIdx.x == 0) claimed_s = __hip_atomic_load(&clip_state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const unsigned long long claimed = claimed_s;
@@ -978,6 +1053,8 @@ hipError_t launch_mesh_clear(const MeshWork &w, int S, int width, int height, hi
     return hipGetLastError();
 }
 
+size_t mesh_pairs_entries(long long ntri) { return (size_t)((ntri + 255) / 256) * kMaxViewsPerLaunch; }
+
 hipError_t launch_render_mesh(const float *xyz, const float *uv, long long ntri, const float *luma, int levels, const int *lw,
                               const int *lh, const long long *loff, const float *mvps, int S, const MeshWork &w, int layout_views,
                               int bin_cap_limit, unsigned long long clip_cap_limit, uint8_t *out, int width, int height, hipStream_t stream,
@@ -1011,15 +1088,34 @@ hipError_t launch_render_mesh(const float *xyz, const float *uv, long long ntri,
         g.zbuf = w.zbuf + (size_t)s0 * width * height;
         if (ntri > 0) {
             ClipItem *clipq = static_cast<ClipItem *>(w.clip_queue);
-            // shares of the views: aim at ~half a million lanes
-            static const long long lanes_wanted = getenv("NMI_MESH_LANES") ? atoll(getenv("NMI_MESH_LANES")) : 500000;
-            long long shares = (lanes_wanted + ntri - 1) / ntri;
-            shares = shares < 1 ? 1 : (shares > views ? views : shares);
-            hipLaunchKernelGGL(nmi_mesh_bin_kernel, dim3((unsigned)(wf.blocks + ((ntri + 255) / 256) * shares)), dim3(256), 0, stream, xyz, uv, ntri,
-                               mvps + (size_t)s0 * 16, views, width, height, g, clipq, w.clip_state, clip_cap, (int)shares, wf);
+            const long long nblocks = (ntri + 255) / 256;
+            static const bool no_pairs = getenv("NMI_MESH_NO_PAIRS") != nullptr;   // measurement switch: the one-kernel form
+            const long long cus = w.compute_units > 0 ? w.compute_units : 256;
+            // (a small mesh -- fewer (block, view) pairs than four workgroups per CU -- already runs one view deep in the one-kernel
+            // form, whose view shares make a workgroup per pair, and would only pay for the second launch: 119.7 vs 121.9 us at 4,800 triangles)
+            if (w.pairs && w.pair_state && (unsigned long long)nblocks * kMaxViewsPerLaunch <= w.pairs_cap && nblocks < (1ll << 25) && !no_pairs &&
+                nblocks * views > 4 * cus) {
+                // two kernels: (block, view) pairs that can see each other, then a bounded number of workers over them (16 per CU:
+                // 8 resident, the workers are bound by their round trips; 4 / 8 / 16 per CU: 149.3 / 147.2 / 146.2 us at 120 k
+                // triangles, 803 / 778 / 756 us at 7.7 M)
+                static const int per_cu = getenv("NMI_MESH_WORKERS") ? atoi(getenv("NMI_MESH_WORKERS")) : 16;
+                long long workers = cus * (per_cu > 0 ? per_cu : 16);
+                if (workers > nblocks * views) workers = nblocks * views;
+                hipLaunchKernelGGL(nmi_mesh_cull_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream, xyz, ntri, mvps + (size_t)s0 * 16, views, w.pairs,
+                                   w.pair_state);
+                hipLaunchKernelGGL(nmi_mesh_bin_pairs_kernel, dim3((unsigned)(workers + wf.blocks)), dim3(256), 0, stream, xyz, uv, ntri,
+                                   mvps + (size_t)s0 * 16, width, height, g, clipq, w.clip_state, clip_cap, wf, w.pairs, w.pair_state);
+            } else {
+                // shares of the views: aim at ~half a million lanes
+                static const long long lanes_wanted = getenv("NMI_MESH_LANES") ? atoll(getenv("NMI_MESH_LANES")) : 500000;
+                long long shares = (lanes_wanted + ntri - 1) / ntri;
+                shares = shares < 1 ? 1 : (shares > views ? views : shares);
+                hipLaunchKernelGGL(nmi_mesh_bin_kernel, dim3((unsigned)(wf.blocks + ((ntri + 255) / 256) * shares)), dim3(256), 0, stream, xyz, uv, ntri,
+                                   mvps + (size_t)s0 * 16, views, width, height, g, clipq, w.clip_state, clip_cap, (int)shares, wf);
+            }
             // (crossing triangles are few: an empty pass should cost little)
             hipLaunchKernelGGL(nmi_mesh_clip_kernel, dim3(64), dim3(256), 0, stream, xyz, uv, ntri, mvps + (size_t)s0 * 16, views, width,
-                               height, g, clipq, w.clip_state, clip_cap);
+                               height, g, clipq, w.clip_state, clip_cap, w.pair_state);
         }
         hipLaunchKernelGGL(nmi_mesh_tile_kernel, dim3((unsigned)(views * tiles)), dim3(kTileThreads), 0, stream, xyz, uv, mvps + (size_t)s0 * 16,
                            out + (size_t)s0 * width * height, width, height, tex, g);
