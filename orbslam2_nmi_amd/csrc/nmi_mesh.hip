@@ -748,9 +748,10 @@ enum : int {
     R_WORDS = 28,
 };
 
+template <int BINMAX>
 struct TileLds {
     unsigned long long keys[kTile * kTile];
-    uint32_t rec[kBinMax][R_WORDS];
+    uint32_t rec[BINMAX][R_WORDS];
     uint32_t wave_sum[kTileThreads / 64];
     uint32_t hdr[4];
     TexLevel tex[16];
@@ -770,11 +771,12 @@ __device__ __forceinline__ void planes_from_lds(const uint32_t *r, Planes &P)
 
 }  // namespace
 
-__global__ __launch_bounds__(kTileThreads) void nmi_mesh_tile_kernel(const float *__restrict__ xyz, const float *__restrict__ uv,
+template <int BINMAX>
+__device__ __forceinline__ void mesh_tile_body(const float *__restrict__ xyz, const float *__restrict__ uv,
                                                                      const float *__restrict__ mvps, uint8_t *__restrict__ out, int width,
                                                                      int height, MeshTexture tex, BinGrid g)
 {
-    __shared__ TileLds lds;
+    __shared__ TileLds<BINMAX> lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = g.tiles_x * g.tiles_y;
     const int bin = blockIdx.x;
@@ -854,7 +856,7 @@ __global__ __launch_bounds__(kTileThreads) void nmi_mesh_tile_kernel(const float
         __syncthreads();
         uint32_t before = 0, total = 0;
 #pragma unroll
-        for (int w = 0; w < kBinMax / 64; ++w) {
+        for (int w = 0; w < (BINMAX + 63) / 64; ++w) {
             const uint32_t ws = lds.wave_sum[w];
             before += w < wave ? ws : 0u;
             total += ws;
@@ -1008,6 +1010,28 @@ __global__ __launch_bounds__(kTileThreads) void nmi_mesh_tile_kernel(const float
     }
 }
 
+// Two builds of the tile kernel.  The usual one holds 255 bin entries per tile (62 KB of LDS: two workgroups per CU).  For a mesh
+// whose tiles cannot fill that -- launch_render_mesh decides from the triangle count -- the small one holds 127 (48 KB) and is
+// held to 80 registers, so that THREE workgroups share a CU: the kernel spends half its wave-cycles waiting (set-up, barriers,
+// texel fetches), and a third workgroup to switch to is worth more than the spills the register cap costs (93.5 -> 81.5 us at
+// 4,800 triangles, same box).
+__global__ __launch_bounds__(kTileThreads) void nmi_mesh_tile_kernel(const float *__restrict__ xyz, const float *__restrict__ uv,
+                                                                     const float *__restrict__ mvps, uint8_t *__restrict__ out, int width,
+                                                                     int height, MeshTexture tex, BinGrid g)
+{
+    mesh_tile_body<kBinMax>(xyz, uv, mvps, out, width, height, tex, g);
+}
+
+constexpr int kBinSmall = 128;
+
+__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(6, 6))) void nmi_mesh_tile_small_kernel(
+    const float *__restrict__ xyz, const float *__restrict__ uv, const float *__restrict__ mvps, uint8_t *__restrict__ out, int width, int height,
+    MeshTexture tex, BinGrid g)
+{
+    mesh_tile_body<kBinSmall>(xyz, uv, mvps, out, width, height, tex, g);
+}
+
+
 __global__ __launch_bounds__(256) void nmi_mesh_clear_kernel(unsigned long long *zbuf, size_t n, uint32_t *state, size_t n_state,
                                                              unsigned long long *clip_state)
 {
@@ -1080,6 +1104,11 @@ hipError_t launch_render_mesh(const float *xyz, const float *uv, long long ntri,
     g.cap = g.stride - 1 < bin_cap_limit ? g.stride - 1 : bin_cap_limit;
     if (g.cap < 0) g.cap = 0;
     const int tiles = g.tiles_x * g.tiles_y;
+    // The small tile kernel (127 entries per tile, three workgroups per CU) for meshes that could not fill more even if every
+    // triangle were in view and touched two tiles; a fuller bin than its capacity takes the per-lane path as always.
+    static const bool no_small = getenv("NMI_MESH_NO_SMALL_TILES") != nullptr;   // measurement switch
+    const bool small_tiles = !no_small && (ntri * 2 <= (long long)(kBinSmall - 1) * tiles || g.cap <= kBinSmall - 1);
+    if (small_tiles && g.cap > kBinSmall - 1) g.cap = kBinSmall - 1;
     const unsigned long long clip_cap = w.clip_cap < clip_cap_limit ? w.clip_cap : clip_cap_limit;
     for (int s0 = 0; s0 < S; s0 += kMaxViewsPerLaunch) {
         const int views = S - s0 < kMaxViewsPerLaunch ? S - s0 : kMaxViewsPerLaunch;
@@ -1117,8 +1146,12 @@ hipError_t launch_render_mesh(const float *xyz, const float *uv, long long ntri,
             hipLaunchKernelGGL(nmi_mesh_clip_kernel, dim3(64), dim3(256), 0, stream, xyz, uv, ntri, mvps + (size_t)s0 * 16, views, width,
                                height, g, clipq, w.clip_state, clip_cap, w.pair_state);
         }
-        hipLaunchKernelGGL(nmi_mesh_tile_kernel, dim3((unsigned)(views * tiles)), dim3(kTileThreads), 0, stream, xyz, uv, mvps + (size_t)s0 * 16,
-                           out + (size_t)s0 * width * height, width, height, tex, g);
+        if (small_tiles)
+            hipLaunchKernelGGL(nmi_mesh_tile_small_kernel, dim3((unsigned)(views * tiles)), dim3(kTileThreads), 0, stream, xyz, uv,
+                               mvps + (size_t)s0 * 16, out + (size_t)s0 * width * height, width, height, tex, g);
+        else
+            hipLaunchKernelGGL(nmi_mesh_tile_kernel, dim3((unsigned)(views * tiles)), dim3(kTileThreads), 0, stream, xyz, uv, mvps + (size_t)s0 * 16,
+                               out + (size_t)s0 * width * height, width, height, tex, g);
     }
     return hipGetLastError();
 }
