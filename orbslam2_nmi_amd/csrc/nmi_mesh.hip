@@ -14,19 +14,23 @@
 // pixels alone, shading each covered one and resolving visibility with a device atomicMin on a 44 MB depth|luma buffer:
 // 0.34-0.74 ms per 27 views, "arithmetic, not memory and not atomics" -- ~40 instructions of edge functions per
 // bounding-box pixel and ~350 of attributes, LOD and texture per COVERED fragment, on lanes that mostly sat idle.  Now:
-//   nmi_mesh_bin_kernel   one lane per triangle, looping over the views (the mesh is read once; blocks of 256 triangles are
-//                         frustum-culled per view).  It only decides where a triangle goes: a triangle whose pixel box is
-//                         at most kSmallBox pixels is rasterised right there (coverage + depth only) into a 64-bit key
-//                         buffer in memory; a larger one is appended to the BIN of every 64 x 64 screen tile its box
-//                         touches (wave-aggregated appends: neighbours in the mesh land in the same tile); one that crosses
-//                         the near plane goes to a small queue for
-//   nmi_mesh_clip_kernel  which clips it (Sutherland-Hodgman in clip space) and treats the 1 or 2 pieces the same way.
+//   binning pass          one lane per triangle; blocks of 256 triangles are frustum-culled per view.  It only decides where a
+//                         triangle goes: one whose pixel box is at most kSmallBox pixels is rasterised right there
+//                         (coverage + depth only) into a 64-bit key buffer in memory; a larger one is appended to the BIN of
+//                         every 64 x 64 screen tile its box touches (wave-aggregated appends: neighbours in the mesh land in
+//                         the same tile); one that crosses the near plane goes to a small queue for the clip kernel.
+//                         Small meshes: ONE kernel, nmi_mesh_bin_kernel, a workgroup per block of triangles and share of the
+//                         views.  Larger ones: TWO -- nmi_mesh_cull_kernel lists the (block, view) pairs in reach of each
+//                         other, nmi_mesh_bin_pairs_kernel deals them out to a bounded number of worker workgroups, every
+//                         unit of work one view deep.
+//   nmi_mesh_clip_kernel  clips a crossing triangle (Sutherland-Hodgman in clip space) and treats the 1 or 2 pieces the same way.
 //   nmi_mesh_tile_kernel  one 512-lane workgroup per (view, tile): the tile's 4096 visibility keys live in LDS (32 KiB, no
-//                         device atomics, no clear pass), lane j sets up bin entry j into an LDS record, the 512 lanes share
-//                         the pixels of the records' boxes evenly and resolve visibility with ds_min_u64, then
-//                         every pixel is shaded ONCE, by the triangle that won it (deferred: attributes, LOD and texture are
-//                         not spent on hidden or uncovered pixels, and every lane has a pixel), and leaves as a byte of the
-//                         render -- four pixels side by side per lane and step, one dword store.
+//                         device atomics, no clear pass), lane j sets up bin entry j into an LDS record, the 512 lanes deal
+//                         out the pixel pairs of the records' boxes in uniform chunks and resolve visibility with ds_min_u64,
+//                         then every pixel is shaded ONCE, by the triangle that won it (deferred: attributes, LOD and texture
+//                         are not spent on hidden or uncovered pixels, and every lane has a pixel), and leaves as a byte of
+//                         the render -- four pixels side by side per lane and step, one dword store.  Two builds: 255 bin
+//                         entries per tile (two workgroups per CU) or 127 (nmi_mesh_tile_small_kernel: three).
 // Visibility key = depth24 << 40 | triangle << 10 | piece << 9 | slot: smaller depth wins, equal depths go to the triangle
 // drawn first (GL_LESS keeps the earlier fragment of glDrawArrays' order) -- deterministic whatever the order of the
 // atomics.  Pixels won through the memory buffer (small triangles, bin overflow) carry slot 0x1FF and set their triangle up
