@@ -642,3 +642,52 @@ def test_gpu_reciprocal_exhaustive():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "RCP OK" in r.stdout, r.stdout + r.stderr
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The renderers choose between internal forms by the size of the job (binning in one kernel or two, tile kernel with 255 or 127
+# entries per tile; a level's cloud through the prep kernel's list).  The choice must not show in a single byte.
+
+@pytest.mark.gpu
+def test_gpu_mesh_pass_variants_agree():
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = os.path.join(ROOT, "tests", "helpers", "mesh_variants.py")
+    outs = []
+    for extra in ({}, {"NMI_MESH_NO_PAIRS": "1", "NMI_MESH_NO_SMALL_TILES": "1"}, {"NMI_MESH_NO_PAIRS": "1"}, {"NMI_MESH_NO_SMALL_TILES": "1"}):
+        r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600, env=dict(os.environ, **extra))
+        assert r.returncode == 0, r.stdout + r.stderr
+        lines = [l for l in r.stdout.splitlines() if l.startswith("MESH")]
+        assert len(lines) == 5, r.stdout + r.stderr
+        outs.append(lines)
+    assert all(o == outs[0] for o in outs[1:]), outs
+
+
+@pytest.mark.gpu
+def test_gpu_level_cloud_odd_sizes_equal_render_points():
+    """Clouds of 1 .. 1,000 points (fewer points than a wavefront, ragged last wavefront, fewer wavefronts than splat workers), 1 and
+    64 views, sprite sizes 1, 2 and 5: a level's renders are nmi_render_points'."""
+    torch = pytest.importorskip("torch")
+    import orbslam2_nmi_amd as nmi
+    w, h = 160, 120
+    K = sy.intrinsics(w, h)
+    rng = np.random.default_rng(1)
+    for n in (1, 63, 65, 1000):
+        for S in (1, 64):
+            for size in (1.0, 2.0, 5.0):
+                rp = capi.RenderParams(fx=K[0, 0], fy=K[1, 1], cx=K[0, 2], cy=K[1, 2], near_plane=0.5, far_plane=40.0, point_size=size)
+                xyz = (rng.uniform(-1, 1, (n, 3)) * [6, 4, 6] + [0, 0, 9]).astype(np.float32)
+                red = rng.uniform(0, 1, n).astype(np.float32)
+                mvps = np.stack([capi.render_mvp(rp, rng.uniform(-1, 1, 3), rng.uniform(-1, 1, 3) * [0.3, 0.3, 0] + [0, 0, 4], (0, -1, 0), (0, 0, 0))
+                                 for _ in range(S)])
+                Ms = capi.warp_homographies(K, (1, 1, 1), (0.02, 0.02, 0.05))
+                with nmi.NmiContext(w, h) as ctx:
+                    dx, dr = torch.from_numpy(xyz).cuda(), torch.from_numpy(red).cuda()
+                    frame = ctx.render_points(dx, dr, mvps[:1], size)[0].contiguous()
+                    want = ctx.render_points(dx, dr, mvps, size).cpu().numpy()
+                    with nmi.NmiLevel(ctx, dx, dr, frame, S, 1, size) as lv:
+                        for rep in range(2):
+                            lv.run(mvps, Ms)
+                            assert np.array_equal(lv.outputs()[0], want), (n, S, size, rep)
