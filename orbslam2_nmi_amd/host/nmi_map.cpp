@@ -71,7 +71,7 @@ int nmi_map_load_obj(const char *path, float **xyz, float **uv, int64_t *n_verti
                 ipos.insert(ipos.end(), a, a + 3);
                 itex.insert(itex.end(), b, b + 3);
             } else {
-                char rest[1000];  // probably a comment: eat up the rest of the line
+                char rest[1000];  // any other keyword (comments, vn, usemtl, s, g ...): the remainder of its line is dropped
                 if (!fgets(rest, sizeof rest, in.f)) break;
             }
         }
