@@ -546,6 +546,22 @@ class NmiLevel:
         self.ctx._check(self._lib.nmi_level_run(self._h, mp, hp, C.byref(idx), C.byref(sc)), "nmi_level_run")
         return int(idx.value), np.float32(sc.value)
 
+    def bind(self, mvps, homographies, comm=None):
+        """Parameters converted ONCE -> a callable that replays the level with them: () -> (global index, score).  For loops that
+        replay a few fixed parameter sets many times (bench.py --config e2e): the conversions of run() cost the interpreter ~20 us a
+        call, a tenth of the level."""
+        m, h, mp, hp = self._params(mvps, homographies)
+        idx, sc = C.c_int64(0), C.c_float(0)
+        pidx, psc, lib, handle, check = C.byref(idx), C.byref(sc), self._lib, self._h, self.ctx._check
+
+        def replay(_keep=(m, h)):   # (the arrays behind the pointers stay alive with the closure)
+            if comm is None:
+                check(lib.nmi_level_run(handle, mp, hp, pidx, psc), "nmi_level_run")
+            else:
+                check(lib.nmi_level_run_rccl(handle, mp, hp, comm, pidx, psc), "nmi_level_run_rccl")
+            return idx.value, sc.value
+        return replay
+
     def run_rccl(self, mvps, homographies, comm):
         """The same + the level's MAX all-reduce over the RCCL communicator -> the LEVEL's winner, on every rank."""
         m, h, mp, hp = self._params(mvps, homographies)
