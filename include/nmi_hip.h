@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define NMI_HIP_ABI_VERSION 1
+#define NMI_HIP_ABI_VERSION 2 /* 2 (round 4): + nmi_pix_status, NMI_OPT_SPLIT 1; round 3 had added nmi_split_status,
+                                 nmi_level_create_block, nmi_level_create_mesh_block, nmi_level_run_rccl, nmi_stream_submit_block and
+                                 changed NMI_OPT_TILE_QUEUE from queue items to entries per tile bin without a bump */
 
 /* Error codes.  HIP errors are reported as NMI_ERR_HIP - (int)hipError_t, RCCL as NMI_ERR_RCCL - (int)ncclResult_t. */
 #define NMI_OK 0
@@ -363,15 +365,18 @@ int nmi_last_kernel_ms(nmi_ctx *ctx, float *h_ms);
 #define NMI_OPT_SPLIT 7        /* small grids (nmi_eval_pair, collapsed search levels): K workgroups per candidate, each owning
                                   256 / K rows of the joint histogram, optionally x P pixel ranges (NMI_OPT_SPLIT_PIXELS);
                                   bit-identical results.  -1 (default, on 256 compute units): 8 x 4 up to 8 candidates, 8 x 2
-                                  up to 16, 4 x 2 up to 32, 4 x 1 up to 64, none for larger grids; 0: never; 2 / 4 / 8: that
-                                  K whenever the grid fits. */
+                                  up to 16, 4 x 2 up to 32; 33 ... 128 candidates: 1 x P, pixel ranges only (nmi_pix_status; P = 4
+                                  up to 64 candidates, 3 up to 85, 2 up to 128); none for larger grids; 0: never; 2 / 4 / 8: that
+                                  K whenever the grid fits; 1: pixel ranges only, NMI_OPT_SPLIT_PIXELS = 2 ... 5 of them, whenever
+                                  the grid fits. */
 #define NMI_OPT_WAIT_MODE 8    /* how a blocking call waits for the posted result: 0 (default) spins on the pinned word
                                   (lowest latency, occupies the calling core for the search), 1 yields the core between
                                   polls (sched_yield; for hosts whose other threads need the core, e.g. ORB-SLAM2's
                                   LocalMapping / LoopClosing).  NMI_OPT_RESULT_PATH 0 sleeps in hipStreamSynchronize instead. */
 #define NMI_OPT_SPLIT_PIXELS 10 /* additionally cut the pixels of each pair into 2 or 4 ranges (one workgroup per row part and
                                   range, merged per row part: nmi_eval_pair = 8 x 4 = 32 workgroups; 4 with 8 row parts only).
-                                  -1 (default): see NMI_OPT_SPLIT; 1: never; 2 / 4: that many when it exists and fits. */
+                                  -1 (default): see NMI_OPT_SPLIT; 1: never; 2 / 4: that many when it exists and fits
+                                  (NMI_OPT_SPLIT 1: 2 ... 5). */
 #define NMI_OPT_CONTENT_PATH 12 /* frames with few distinct intensities (posterised, thresholded, quantised): -1 (default)
                                   automatic -- every search by the general kernel also counts the distinct intensities (bins) its
                                   candidates' marginal histograms hold, (nr, nw), at no extra launch, and every few-levels search
@@ -381,6 +386,9 @@ int nmi_last_kernel_ms(nmi_ctx *ctx, float *h_ms);
                                   path either way.  0: never; 1: always try it first.  Every few-levels search falls back to the
                                   general kernel on the device when its stacks do not qualify: results never depend on it. */
 #define NMI_OPT_FEWLEVELS_BINS 13 /* largest nr * nw sent down the few-levels path (1..4096, default 4096) */
+#define NMI_OPT_PIX_OWNER_BIAS 14 /* pixel-range kernel (nmi_pix_status): pixels a candidate's owner adds beyond an equal share of the
+                                  pair while its helpers' counters travel to it (default 49152 = 3.4 us of one CU's histogram
+                                  phase); a matter of speed only */
 #define NMI_OPT_STAMPS 9       /* profiling tools only: value = device pointer to uint64 [workgroups][8]; workgroups of the
                                   split kernel store wall-clock stamps (100 MHz) at their phase boundaries there; 0 = off */
 int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value);
@@ -390,6 +398,13 @@ int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value);
  * the pause the next timeout would start, *last_launch_parts = row parts per candidate of the most recent launch (0: the
  * one-workgroup kernel scored it).  Any pointer may be null.  Does not wait. */
 int nmi_split_status(nmi_ctx *ctx, int32_t *timeouts, int32_t *cooldown_calls_left, int32_t *next_cooldown, int32_t *last_launch_parts);
+/* Mid-size grids (33 ... 128 candidates on 256 compute units: the live strategy's collapsed-axis levels, Tracking.cc:2014-2043,
+ * and a rank's share of a sharded 729-candidate grid) are scored by P workgroups per candidate, each adding a range of the
+ * pair's PIXELS into a histogram of its own (csrc/nmi_pix_kernel.hip); bit-identical results; no residence condition, so
+ * enqueue-only calls use it too.  *last_launch_ranges = P of the most recent launch (0: another kernel scored it);
+ * *healed = candidates so far whose owner gave up waiting for a helper (2 ms) and scored them alone -- nothing for the
+ * host to redo.  Waits for the context's stream when healed is asked for.  Any pointer may be null. */
+int nmi_pix_status(nmi_ctx *ctx, int32_t *last_launch_ranges, int32_t *healed);
 
 /* Introspection. */
 /* Copies the context's per-count term table, term[c] = (c/len) * log2(c/len) in the reference's fp32 form with

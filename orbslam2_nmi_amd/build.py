@@ -56,28 +56,46 @@ def flags(ablations=False):
 
 
 def compile_and_link(out, ablations=False, force=False, verbose=False, jobs=None):
-    """One object per source under lib/obj/ (recompiled when the source or any header is newer), compiled in parallel, then
-    one link.  Same flags for every translation unit; no relocatable device code (no kernel calls across units)."""
+    """One object per source under lib/obj/ (recompiled when the source, any header or -- for kernels -- any .hip file is
+    newer), compiled in parallel, then one link.  Same flags for every translation unit; no relocatable device code (no
+    kernel calls across units).  Objects and the library are written under private names and renamed, and one builder
+    runs at a time (flock): concurrent callers wait and then find nothing left to do."""
+    import fcntl
     from concurrent.futures import ThreadPoolExecutor
     obj_dir = os.path.join(LIB_DIR, "obj_ablate" if ablations else "obj")
     os.makedirs(obj_dir, exist_ok=True)
-    newest_header = max(os.path.getmtime(f) for f in headers() + [os.path.abspath(__file__)])
-    todo, objs = [], []
-    for src in sources():
-        obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
-        objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
-            todo.append(["hipcc", *flags(ablations), "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
 
-    if todo:
-        with ThreadPoolExecutor(max_workers=jobs or min(6, os.cpu_count() or 1)) as ex:
-            list(ex.map(run, todo))
-    run(["hipcc", "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", out, "-ldl"])
+    def compile_one(job):
+        src, obj = job
+        tmp = f"{obj}.{os.getpid()}.part"
+        run(["hipcc", *flags(ablations), "-c", src, "-o", tmp])
+        os.replace(tmp, obj)
+
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        newest_header = max(os.path.getmtime(f) for f in headers() + [os.path.abspath(__file__)])
+        # some kernel files are compiled more than once through a wrapper that #includes them (nmi_kernels_gated.hip,
+        # nmi_kernels_stamped.hip, nmi_pix_kernel.hip include nmi_kernels.hip): every .hip depends on every .hip
+        newest_hip = max([os.path.getmtime(f) for f in sources() if f.endswith(".hip")] + [newest_header])
+        todo, objs = [], []
+        for src in sources():
+            obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
+            objs.append(obj)
+            dep = newest_hip if src.endswith(".hip") else max(os.path.getmtime(src), newest_header)
+            if force or not os.path.exists(obj) or os.path.getmtime(obj) < dep:
+                todo.append((src, obj))
+        if todo:
+            with ThreadPoolExecutor(max_workers=jobs or min(6, os.cpu_count() or 1)) as ex:
+                list(ex.map(compile_one, todo))
+        if todo or force or not os.path.exists(out) or any(os.path.getmtime(o) > os.path.getmtime(out) for o in objs):
+            tmp = f"{out}.{os.getpid()}.part"
+            run(["hipcc", "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", tmp, "-ldl"])
+            os.replace(tmp, out)
     return out
 
 

@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = (
     "nmi_stream_submit", "nmi_stream_wait", "nmi_stream_keep_ratings", "nmi_stream_copy_ratings", "nmi_key_pack", "nmi_key_unpack", "nmi_search_grid_rccl", "nmi_search_grid_block_rccl",
     "nmi_rccl_unique_id", "nmi_rccl_comm_init", "nmi_rccl_comm_destroy", "nmi_set_profiling", "nmi_last_kernel_ms",
     "nmi_set_option", "nmi_copy_term_table", "nmi_abi_version", "nmi_error_string", "nmi_last_error_detail", "nmi_get_info", "nmi_last_content", "nmi_sort_points", "nmi_sort_triangles",
-    "nmi_split_status", "nmi_level_create_block", "nmi_level_create_mesh_block", "nmi_level_run_rccl", "nmi_stream_submit_block",
+    "nmi_split_status", "nmi_pix_status", "nmi_level_create_block", "nmi_level_create_mesh_block", "nmi_level_run_rccl", "nmi_stream_submit_block",
 )
 
 
@@ -123,6 +123,7 @@ def load_library(build_if_missing=False):
     lib.nmi_get_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     lib.nmi_last_content.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     lib.nmi_split_status.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    lib.nmi_pix_status.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     lib.nmi_sort_points.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
     lib.nmi_sort_triangles.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
     _lib = lib
@@ -251,6 +252,7 @@ class NmiContext:
 
     OPT_HIST_VARIANT, OPT_PHASE_MASK, OPT_WORKGROUPS, OPT_RESULT_PATH, OPT_XCD_TILING, OPT_TILE_QUEUE = 1, 2, 3, 4, 5, 6
     OPT_SPLIT, OPT_WAIT_MODE, OPT_STAMPS, OPT_SPLIT_PIXELS, OPT_CLIP_QUEUE = 7, 8, 9, 10, 11
+    OPT_PIX_OWNER_BIAS = 14
     OPT_CONTENT_PATH, OPT_FEWLEVELS_BINS = 12, 13
 
     def set_option(self, option, value):
@@ -283,6 +285,12 @@ class NmiContext:
         v = [C.c_int32(0) for _ in range(4)]
         self._check(self._lib.nmi_split_status(self._h, *[C.byref(x) for x in v]), "nmi_split_status")
         return dict(zip(("timeouts", "cooldown_calls_left", "next_cooldown", "last_launch_parts"), (x.value for x in v)))
+
+    def pix_status(self):
+        """Pixel-range kernel for mid-size grids -> {"last_launch_ranges", "healed"} (nmi_pix_status; waits for the stream)."""
+        v = [C.c_int32(0) for _ in range(2)]
+        self._check(self._lib.nmi_pix_status(self._h, *[C.byref(x) for x in v]), "nmi_pix_status")
+        return dict(zip(("last_launch_ranges", "healed"), (x.value for x in v)))
 
     def term_table(self):
         """The per-count entropy-term table (NMI.cu:242-263 evaluated once per possible count) as numpy float32 [W*H+1]."""

@@ -83,7 +83,7 @@ static void choose_split(const nmi_ctx *ctx, int64_t total, int cap, int *parts,
     *parts = 0;
     *pix_parts = 1;
     if (cap > ctx->compute_units) cap = ctx->compute_units;  // all workgroups of a split launch must be resident at once
-    if (ctx->hist_variant != 3 || ctx->split_mode == 0 || total <= 0 || total > cap) return;
+    if (ctx->hist_variant != 3 || ctx->split_mode == 0 || ctx->split_mode == 1 || total <= 0 || total > cap) return;
     auto fits = [&](int k, int p) { return nmi::split_workgroups((int)total, k, p) <= cap; };
     auto exists = [](int k, int p) { return p == 1 || (k == 8 && (p == 2 || p == 4)) || (k == 4 && p == 2); };
     const int want_p = ctx->split_pixels;  // -1 automatic, 1 never, 2 / 4 that many when it fits
@@ -108,6 +108,24 @@ static void choose_split(const nmi_ctx *ctx, int64_t total, int cap, int *parts,
             return;
         }
     }
+}
+
+// Pixel ranges per candidate for nmi_pix_kernel (nmi_pix_kernel.hip), 0 = another kernel.  The owner of a candidate adds
+// its P - 1 helpers' histograms to its own (~1.3 us each), so P grows only while the histogram phase (21 us / P at 640x480)
+// shrinks faster: automatic choice 4 up to 64 candidates, 3 up to 85, 2 up to 128 (256 CUs); smaller grids keep the
+// row-split forms, larger ones have no CU to spare.  NMI_OPT_SPLIT 1 + NMI_OPT_SPLIT_PIXELS P forces P wherever it fits.
+static int choose_pix(const nmi_ctx *ctx, const nmi::GridArgs &a, int64_t total, int cap)
+{
+    if (cap > ctx->compute_units) cap = ctx->compute_units;  // (an owner that waits for a CU starts a second round)
+    if (ctx->hist_variant != 3 || !a.vec_ok || (ctx->shift != 0 && !ctx->params.use_bg) || ctx->pair_renders || total <= 0) return 0;
+    if ((ctx->phase_mask & ~512) != 3 || (a.dbg_stamps != nullptr && ctx->split_mode != 1)) return 0;
+    if (ctx->split_mode == 1) {
+        const int p = ctx->split_pixels;
+        return (p >= 2 && p <= nmi::pix_max_ranges() && total * p <= cap) ? p : 0;
+    }
+    if (ctx->split_mode != -1 || ctx->split_pixels != -1 || total <= 32 || total * 2 > cap) return 0;
+    const int p = (int)(cap / total);
+    return p > 4 ? 4 : p;
 }
 
 // Epoch of the next split launch.  Slab granules carry all 32 bits, block granules the low 16: neither may be 0 (the
@@ -221,6 +239,7 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
         ctx->posted = post;
         ctx->last_slot = ctx->slot;
         ctx->last_parts = 0;
+        ctx->last_pix = 0;
         ctx->last_epoch = 0;
         return NMI_OK;
     }
@@ -230,12 +249,34 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     // once, i.e. no more of them than compute units (each takes a whole CU)
     choose_split(ctx, total, cap, &parts, &pix_parts);
     if (pix_parts > 1 && ctx->npix >= (1 << 24)) pix_parts = 1;  // block granules hold 24-bit counts
+    int pix = choose_pix(ctx, a, total, cap);  // mid-size grids: pixel ranges (no residence condition, heals itself)
+    if (pix) parts = 0;
     if (parts && !split_checked) parts = 0;  // enqueue-only call: nobody would notice a timed-out hand-off, so no split kernel
     if (parts && ctx->split_cooldown > 0) {  // after a timeout: nmi_grid_kernel for a while, then the split forms again
         --ctx->split_cooldown;
         parts = 0;
     }
     if (!parts) pix_parts = 1;
+    // Few-levels path (nmi_fewlevels_kernel.hip).  The decision rests on what the most recent probe of a search's stacks
+    // found (frames and renders of consecutive searches look alike); it is only a matter of speed, because the probe that
+    // goes with every few-levels launch hands the search back to nmi_grid_kernel (gated launch below) when this
+    // search's stacks do not qualify.
+    bool few = false;
+    const bool few_eligible = !parts && !(pix && ctx->split_mode == 1) && a.vec_ok && (ctx->shift == 0 || p.use_bg) && ctx->hist_variant == 3 && ctx->phase_mask == 3 && !dbg_joint &&
+                              !dbg_h1 && !dbg_h2 && !dbg_sums && !ctx->pair_renders && !ctx->dbg_stamps && ctx->content_path != 0;
+    if (few_eligible) {
+        // What the most recent search found in its stacks (nr, nw), posted by the device: by the probe that goes with every
+        // few-levels launch, or by nmi_grid_kernel itself -- every general search counts the bins of its candidates'
+        // marginals on the way (publish_seen / post_seen), so a change of content shows after ONE search, with no extra launch.
+        const unsigned long long posted = __atomic_load_n(ctx->level_post, __ATOMIC_ACQUIRE);
+        if ((uint32_t)(posted >> 32) != ctx->level_seen) {
+            ctx->level_seen = (uint32_t)(posted >> 32);
+            const uint32_t joint = (uint32_t)((posted >> 16) & 0xFFFFu) * (uint32_t)(posted & 0xFFFFu);
+            ctx->few_hint = joint > 0 && joint <= (uint32_t)ctx->fewlevels_bins;
+        }
+        few = ctx->content_path == 1 || ctx->few_hint;
+    }
+    if (few) pix = 0;  // few distinct intensities: the few-levels kernels are the faster ones at any grid size
     if (ctx->pair_renders && !parts) return NMI_ERR_UNSUPPORTED;  // per-pair pointers exist in the split kernel only (nmi_eval_pairs decides first)
     int workgroups = (int)(total < cap ? total : cap);
     if (parts) {
@@ -248,6 +289,16 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
         a.blocks = ctx->d_blocks;
         a.split_error = ctx->d_split_error;
         workgroups = nmi::split_workgroups((int)total, parts, pix_parts);
+    } else if (pix) {
+        int rs = ensure_blocks(ctx, nmi::pix_block_bytes((int)total, pix));
+        if (rs == NMI_OK) rs = next_split_epoch(ctx, &a.epoch);
+        if (rs == NMI_OK && !ctx->d_pix_timeouts) {
+            NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_pix_timeouts, sizeof(uint32_t)));
+            NMI_HIP_TRY(ctx, hipMemsetAsync(ctx->d_pix_timeouts, 0, sizeof(uint32_t), ctx->stream));
+        }
+        if (rs != NMI_OK) return rs;
+        a.blocks = ctx->d_blocks;
+        workgroups = (int)total * pix;
     } else if (ctx->xcd_tiling && total <= (1ll << 24)) {  // 4 B per candidate
         const int orc = ensure_order(ctx, S_local, Wn, &a.order);
         if (orc != NMI_OK) return orc;
@@ -264,25 +315,6 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
         a.scratch = ctx->d_scratch;
     }
 #endif
-    // Few-levels path (nmi_fewlevels_kernel.hip).  The decision rests on what the most recent probe of a search's stacks
-    // found (frames and renders of consecutive searches look alike); it is only a matter of speed, because the probe that
-    // goes with every few-levels launch hands the search back to nmi_grid_kernel (gated launch below) when this
-    // search's stacks do not qualify.
-    bool few = false;
-    const bool few_eligible = !parts && a.vec_ok && (ctx->shift == 0 || p.use_bg) && ctx->hist_variant == 3 && ctx->phase_mask == 3 && !dbg_joint &&
-                              !dbg_h1 && !dbg_h2 && !dbg_sums && !ctx->pair_renders && !ctx->dbg_stamps && ctx->content_path != 0;
-    if (few_eligible) {
-        // What the most recent search found in its stacks (nr, nw), posted by the device: by the probe that goes with every
-        // few-levels launch, or by nmi_grid_kernel itself -- every general search counts the bins of its candidates'
-        // marginals on the way (publish_seen / post_seen), so a change of content shows after ONE search, with no extra launch.
-        const unsigned long long posted = __atomic_load_n(ctx->level_post, __ATOMIC_ACQUIRE);
-        if ((uint32_t)(posted >> 32) != ctx->level_seen) {
-            ctx->level_seen = (uint32_t)(posted >> 32);
-            const uint32_t joint = (uint32_t)((posted >> 16) & 0xFFFFu) * (uint32_t)(posted & 0xFFFFu);
-            ctx->few_hint = joint > 0 && joint <= (uint32_t)ctx->fewlevels_bins;
-        }
-        few = ctx->content_path == 1 || ctx->few_hint;
-    }
     if (!parts && !few && ctx->hist_variant == 3 && ctx->content_path != 0) a.plan = ctx->d_plan;  // the search doubles as a probe
     if (few) {
         const size_t need = (size_t)(S_local + Wn) * (size_t)ctx->npix;
@@ -304,6 +336,10 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
                                             (uint32_t)ctx->fewlevels_bins, few, ctx->stream));
     if (parts) {
         NMI_HIP_TRY(ctx, nmi::launch_split(a, parts, pix_parts, workgroups, p.use_bg != 0, ctx->stream));
+    } else if (pix) {
+        // the owner's range: an equal share plus what it can add while its helpers' counters travel (NMI_OPT_PIX_OWNER_BIAS pixels)
+        const int64_t owner_px = ((int64_t)ctx->npix + (int64_t)(pix - 1) * ctx->pix_owner_bias) / pix;
+        NMI_HIP_TRY(ctx, nmi::launch_pix(a, pix, (int)((owner_px < ctx->npix ? owner_px : ctx->npix) >> 4), p.use_bg != 0, nullptr, ctx->d_pix_timeouts, ctx->stream));
     } else if (few) {
         NMI_HIP_TRY(ctx, nmi::launch_fewlevels(a, ctx->d_rank_stacks, ctx->d_rank_stacks + (size_t)S_local * ctx->npix, workgroups,
                                                p.use_bg != 0, ctx->stream));
@@ -319,6 +355,7 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     ctx->last_slot = ctx->slot;
     ctx->slot ^= 1;
     ctx->last_parts = parts;
+    ctx->last_pix = pix;
     ctx->last_epoch = parts ? a.epoch : 0;
     if (ctx->profiling) {
         NMI_HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
@@ -587,6 +624,7 @@ int nmi_destroy(nmi_ctx *ctx)
     if (ctx->h_pair_table) (void)hipHostFree(ctx->h_pair_table);
     if (ctx->d_pair_scores) (void)hipFree(ctx->d_pair_scores);
     if (ctx->d_blocks) (void)hipFree(ctx->d_blocks);
+    if (ctx->d_pix_timeouts) (void)hipFree(ctx->d_pix_timeouts);
     if (ctx->h_split_error) (void)hipHostFree(ctx->h_split_error);
     if (ctx->level_post) (void)hipHostFree(ctx->level_post);
     if (ctx->d_plan) (void)hipFree(ctx->d_plan);
@@ -645,12 +683,16 @@ int nmi_set_option(nmi_ctx *ctx, int32_t option, int64_t value)
         ctx->hist_variant = (int)value;
         return NMI_OK;
     case NMI_OPT_SPLIT:
-        if (value != -1 && value != 0 && value != 2 && value != 4 && value != 8) return NMI_ERR_INVALID_ARGUMENT;
+        if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return NMI_ERR_INVALID_ARGUMENT;
         ctx->split_mode = (int)value;
         return NMI_OK;
     case NMI_OPT_SPLIT_PIXELS:
-        if (value != -1 && value != 1 && value != 2 && value != 4) return NMI_ERR_INVALID_ARGUMENT;
+        if (value != -1 && (value < 1 || value > 8)) return NMI_ERR_INVALID_ARGUMENT;  // 3, 5 ... 8: with NMI_OPT_SPLIT 1 only
         ctx->split_pixels = (int)value;
+        return NMI_OK;
+    case NMI_OPT_PIX_OWNER_BIAS:
+        if (value < 0 || value > (1 << 24)) return NMI_ERR_INVALID_ARGUMENT;
+        ctx->pix_owner_bias = (int)value;
         return NMI_OK;
     case NMI_OPT_STAMPS:
         ctx->dbg_stamps = (unsigned long long *)(uintptr_t)value;
@@ -840,6 +882,23 @@ int nmi_split_status(nmi_ctx *ctx, int32_t *timeouts, int32_t *cooldown_calls_le
     if (cooldown_calls_left) *cooldown_calls_left = (int32_t)ctx->split_cooldown;
     if (next_cooldown) *next_cooldown = (int32_t)ctx->split_backoff;
     if (last_launch_parts) *last_launch_parts = ctx->last_parts;
+    return NMI_OK;
+}
+
+int nmi_pix_status(nmi_ctx *ctx, int32_t *last_launch_ranges, int32_t *healed)
+{
+    if (!ctx) return NMI_ERR_INVALID_ARGUMENT;
+    if (last_launch_ranges) *last_launch_ranges = ctx->last_pix;
+    if (healed) {
+        *healed = 0;
+        if (ctx->d_pix_timeouts) {
+            DeviceGuard guard(ctx->device);
+            uint32_t n = 0;
+            NMI_HIP_TRY(ctx, hipMemcpyAsync(&n, ctx->d_pix_timeouts, sizeof n, hipMemcpyDeviceToHost, ctx->stream));
+            NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            *healed = (int32_t)n;
+        }
+    }
     return NMI_OK;
 }
 

@@ -41,7 +41,10 @@ struct nmi_ctx {
     unsigned int seq = 0;                  // launches that post to the mailbox so far (blocking calls only)
     int slot = 0;                          // key slot of the next launch
     int last_slot = 0;                     // key slot of the most recent launch
-    int last_parts = 0;                    // parts per candidate of the most recent launch (0 = one workgroup per candidate)
+    int last_parts = 0;                    // row parts per candidate of the most recent launch (0 = not the row-split kernel)
+    int pix_owner_bias = 49152;            // NMI_OPT_PIX_OWNER_BIAS: pixels the owner of a candidate adds beyond an equal share
+    int last_pix = 0;                      // pixel ranges per candidate when it was nmi_pix_kernel (0 = it was not)
+    uint32_t *d_pix_timeouts = nullptr;    // candidates whose owner gave up on a helper and scored them alone (nmi_pix_kernel)
     uint32_t last_epoch = 0;               // its split epoch (meaningful when last_parts != 0)
     // Split-kernel liveness (nmi_split_kernel.hip: its consumers spin, so a launch whose workgroups are not all resident
     // times out after 2 ms).  A timeout is attributed to ITS launch (epoch), that search is redone by nmi_grid_kernel, and the
@@ -83,7 +86,7 @@ struct nmi_ctx {
     int pairs_cap = 0;
     const uint8_t *const *pair_renders = nullptr, *const *pair_warps = nullptr;            // device views for the launch being enqueued
     const uint8_t *const *pair_renders_host = nullptr, *const *pair_warps_host = nullptr;  // the caller's arrays (alignment check)
-    int split_pixels = -1;                // NMI_OPT_SPLIT_PIXELS: -1 automatic, 1 / 2 / 4
+    int split_pixels = -1;                // NMI_OPT_SPLIT_PIXELS: -1 automatic, 1 / 2 / 4 (with NMI_OPT_SPLIT 1: 2 ... 8)
     // Few-levels path (nmi_fewlevels_kernel.hip): which kernels score a search is decided from what the last probe of
     // the stacks found, posted by the device to *level_post = probe number << 32 | nr << 16 | nw.
     nmi::LevelPlan *d_plan = nullptr;
@@ -97,7 +100,7 @@ struct nmi_ctx {
     size_t rank_bytes = 0;
     int last_few = 0;                     // the most recent launch went down the few-levels path (it may have fallen back)
     unsigned long long *dbg_stamps = nullptr;  // NMI_OPT_STAMPS
-    int split_mode = -1;                  // NMI_OPT_SPLIT: -1 automatic, 0 never, 2 / 4 / 8 parts whenever the grid fits
+    int split_mode = -1;                  // NMI_OPT_SPLIT: -1 automatic, 0 never, 2 / 4 / 8 row parts whenever the grid fits, 1: pixel ranges only
     uint32_t *d_zbuf = nullptr;           // depth|colour anchor buffers of the point-cloud renderer (padded, per view)
     int64_t zbuf_cap = 0;
     nmi::MeshWork mesh;                    // mesh renderer (nmi_render_mesh): bins, their state, key buffer, clip queue -- for mesh_views views

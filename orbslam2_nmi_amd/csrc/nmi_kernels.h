@@ -102,6 +102,8 @@ hipError_t launch_grid(const GridArgs &a, int workgroups, bool use_bg, hipStream
 // The same kernel as the fallback behind launch_fewlevels: it returns at once unless a.plan->use == 0.  Fewer than 256 bins
 // only with the background rule on.
 hipError_t launch_grid_gated(const GridArgs &a, int workgroups, bool use_bg, hipStream_t stream);
+// tools only (NMI_OPT_STAMPS): nmi_grid_kernel with wall-clock stamps at its phase boundaries (nmi_kernels_stamped.hip)
+hipError_t launch_grid_stamped(const GridArgs &a, int workgroups, hipStream_t stream);
 
 // Few-levels path (nmi_fewlevels_kernel.hip).  launch_levels probes the stacks (16-byte aligned, npix % 16 == 0) and
 // writes *plan (use = commit && nr * nw <= max_joint) and, if given, the pinned word *post = seq << 32 | nr << 16 | nw.
@@ -127,6 +129,14 @@ struct SplitSlab {
 hipError_t launch_split(const GridArgs &a, int parts, int pix_parts, int workgroups, bool use_bg, hipStream_t stream);
 __host__ __device__ int split_workgroups(int candidates, int parts, int pix_parts);  // grid size of a split launch (one unit per workgroup)
 inline size_t split_block_bytes_per_candidate(int pix_parts) { return (size_t)pix_parts * 256 * 128 * sizeof(unsigned long long); }
+// Pixel-range form for mid-size grids (nmi_pix_kernel.hip): pix_parts workgroups per candidate, each adding a range of the
+// pair's pixels into a whole packed joint histogram; the helpers' histograms travel to the candidate's owner through
+// a.blocks (pix_block_bytes, zero when allocated; tag from a.epoch + *replay).  *timeouts counts candidates whose owner
+// gave up waiting and scored them alone (the launch heals itself).  Needs a.vec_ok, a.order == nullptr, a.epoch != 0.
+// owner_chunks: 16-pixel chunks of the owner's own range (the helpers share the rest).
+hipError_t launch_pix(const GridArgs &a, int pix_parts, int owner_chunks, bool use_bg, const uint32_t *replay, uint32_t *timeouts, hipStream_t stream);
+size_t pix_block_bytes(int candidates, int pix_parts);
+int pix_max_ranges();
 int grid_kernel_lds_bytes();
 size_t grid_kernel_scratch_bytes(int workgroups);
 hipError_t launch_warp(const uint8_t *frame, const float *coeffs /*[Wn][9] inverse maps*/, uint8_t *out, int width,

@@ -261,15 +261,16 @@ __device__ __forceinline__ void add_chunk(Lds &lds, int par, const uint4 &rv, co
 }
 
 // Histogram phase for one candidate: histogram256Kernel's pixel loop, NMI.cu:79-87.
-// NT lanes (tid = 0..NT-1) share the pixels of the candidate.
+// NT lanes (tid = 0..NT-1) share the pixels of the candidate -- on the 16-byte path the 16-pixel chunks [c_first, c_end)
+// of it (the whole pair: 0, npix / 16; nmi_pix_kernel.hip gives each of a candidate's workgroups a range of its own).
 template <bool BG, bool SHIFTED, int HIST, int NT, bool FOLD = true>
 __device__ __forceinline__ void histogram_phase(Lds &lds, int par, const GridArgs &a, const uint8_t *__restrict__ render,
-                                                const uint8_t *__restrict__ warped, int tid)
+                                                const uint8_t *__restrict__ warped, int tid, int c_first, int c_end)
 {
     if (a.vec_ok) {
         // 16 pixels per lane per step: one 16-byte load from each image (1 KiB per wavefront instruction),
         // the next step's loads issued before this step's atomics.
-        const int nchunks = a.npix >> 4;
+        const int nchunks = c_end;
         // 32-bit unsigned byte offsets from the (scalar) image bases: one shift per load instead of 64-bit pointer math
         auto ldw = [&](int c) { return *reinterpret_cast<const uint4 *>(warped + ((uint32_t)c << 4)); };
         // NMI.cu:82: row y of the frame meets row H-1-y of a bottom-up render.  Branch-free for both orientations:
@@ -288,10 +289,10 @@ __device__ __forceinline__ void histogram_phase(Lds &lds, int par, const GridArg
         constexpr bool kHint = FOLD && HIST != 0;
         const bool try_flat = kHint && !(a.phase_mask & 4);  // bit 2: ablation switch (careful loop entered, nothing folded)
         const int last = nchunks - 1;
-        const int iters = (nchunks + NT - 1) / NT;  // workgroup-uniform
-        int resume = (HIST == 1 && kHint) ? tid : -1;  // the exact path is cold anyway: careful from the start
+        const int iters = (nchunks - c_first + NT - 1) / NT;  // workgroup-uniform
+        int resume = (HIST == 1 && kHint) ? c_first + tid : -1;  // the exact path is cold anyway: careful from the start
         if (resume < 0) {
-            int ch = tid;
+            int ch = c_first + tid;
             int c0 = min(ch, last);
             uint4 wa = ldw(c0), ra = ldr(c0), wb, rb;
             for (int it = 0; it < iters; it += 2) {
@@ -548,7 +549,8 @@ __device__ __forceinline__ void final_phase(Lds &lds, const GridArgs &a, int lan
 // the context watches.  Nothing waits for the ORs of other workgroups: a straggling OR can cost a bin in this count or add
 // one to the next search's -- the count is a hint for the host's choice of kernels, every few-levels launch probes its own
 // stacks exactly.
-__device__ __forceinline__ void finish_search(const GridArgs &a, int lane, unsigned long long prev_key)
+// `expected`: workgroups of the launch that call this (all of them: gridDim.x; nmi_pix_kernel: the candidates' owners).
+__device__ __forceinline__ void finish_search(const GridArgs &a, int lane, unsigned long long prev_key, uint32_t expected)
 {
     LevelPlan *plan = const_cast<LevelPlan *>(a.plan);
     uint32_t arrived = 0;
@@ -556,7 +558,7 @@ __device__ __forceinline__ void finish_search(const GridArgs &a, int lane, unsig
         const unsigned int one = prev_key == ~0ull ? 2u : 1u;  // always 1; ties the ticket to this workgroup's maxes (publish_winner)
         arrived = __hip_atomic_fetch_add(a.done, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (__builtin_amdgcn_readfirstlane(arrived) != gridDim.x - 1) return;
+    if (__builtin_amdgcn_readfirstlane(arrived) != expected - 1) return;
     unsigned long long final_key = 0;
     uint32_t bits = 0;
     unsigned long long *post = nullptr;
@@ -596,7 +598,7 @@ __device__ __forceinline__ void exact_candidate(Lds &lds, const GridArgs &a, int
     const int lane = tid & 63, wave = tid >> 6;
     const int w = p / a.S_local, s = p - w * a.S_local;
     __syncthreads();  // wavefront 0 may still be finishing the previous candidate's final phase (it resets shared state)
-    histogram_phase<true, SHIFTED, 1, kBlock>(lds, 0, a, a.render_stack + (size_t)s * a.npix, a.warp_stack + (size_t)w * a.npix, tid);
+    histogram_phase<true, SHIFTED, 1, kBlock>(lds, 0, a, a.render_stack + (size_t)s * a.npix, a.warp_stack + (size_t)w * a.npix, tid, 0, a.npix >> 4);
     __syncthreads();
     decode_phase<!BG>(lds, 0, a, wave, lane);
     __syncthreads();
@@ -627,10 +629,27 @@ __device__ __forceinline__ void exact_candidate(Lds &lds, const GridArgs &a, int
 // name nmi_grid_kernel_gated, which returns at once unless the few-levels kernels enqueued before it handed the search
 // back (plan->use == 0, nmi_fewlevels_kernel.hip).  A second translation unit rather than a template parameter because
 // this kernel sits at its register cap: the mere presence of more instantiations in this unit changed its allocation.
-#ifdef NMI_GRID_KERNEL_GATED
+//
+// nmi_kernels_stamped.hip compiles it a third time (NMI_GRID_KERNEL_STAMPED) as nmi_grid_kernel_stamped: the same code plus
+// wall-clock stamps of every workgroup's first candidate at the phase boundaries (NMI_OPT_STAMPS, tools/grid_stamps.py).
+// nmi_pix_kernel.hip includes this file for its device functions only (NMI_KERNELS_DEVICE_ONLY).
+#ifndef NMI_KERNELS_DEVICE_ONLY
+#if defined(NMI_GRID_KERNEL_GATED)
 #define NMI_GRID_KERNEL_NAME nmi_grid_kernel_gated
+#elif defined(NMI_GRID_KERNEL_STAMPED)
+#define NMI_GRID_KERNEL_NAME nmi_grid_kernel_stamped
 #else
 #define NMI_GRID_KERNEL_NAME nmi_grid_kernel
+#endif
+#ifdef NMI_GRID_KERNEL_STAMPED
+#define NMI_GRID_STAMP(k)                                                                                         \
+    do {                                                                                                          \
+        if (a.dbg_stamps && tid == 0 && stamp_on) a.dbg_stamps[blockIdx.x * 8 + (k)] = wall_clock64();            \
+    } while (0)
+#else
+#define NMI_GRID_STAMP(k) \
+    do {                  \
+    } while (0)
 #endif
 template <bool BG, bool SHIFTED, int HIST>
 __global__ __launch_bounds__(NMI_BLOCK_THREADS) void NMI_GRID_KERNEL_NAME(GridArgs a)
@@ -642,6 +661,10 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void NMI_GRID_KERNEL_NAME(GridAr
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+#ifdef NMI_GRID_KERNEL_STAMPED
+    bool stamp_on = true;  // first candidate of this workgroup only
+#endif
+    NMI_GRID_STAMP(0);
     constexpr bool kOptimistic = HIST == 3;
     constexpr int kFirst = kOptimistic ? 2 : HIST;
     // Background rule off (NMI.cu:85) on the optimistic path: every pixel is counted, so that the wrap detector knows the
@@ -671,6 +694,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void NMI_GRID_KERNEL_NAME(GridAr
     bool table_pending = true;
     int exact_from = -1;  // first ordinal of this workgroup that needs the exact path (workgroup-uniform)
     __syncthreads();
+    NMI_GRID_STAMP(1);
 
     const int total = a.S_local * a.Wn;
     unsigned long long prev_key = 0;
@@ -686,18 +710,21 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void NMI_GRID_KERNEL_NAME(GridAr
 
         if (a.phase_mask & 1) {
             if (a.phase_mask & 8) {  // ablation: only half of the wavefronts take part in the histogram phase
-                if (wave < kWaves / 2) histogram_phase<kCountAll, SHIFTED, kFirst, kBlock / 2>(lds, par, a, render, warped, tid);
+                if (wave < kWaves / 2) histogram_phase<kCountAll, SHIFTED, kFirst, kBlock / 2>(lds, par, a, render, warped, tid, 0, a.npix >> 4);
             } else
-                histogram_phase<kCountAll, SHIFTED, kFirst, kBlock>(lds, par, a, render, warped, tid);
+                histogram_phase<kCountAll, SHIFTED, kFirst, kBlock>(lds, par, a, render, warped, tid, 0, a.npix >> 4);
         }
         if (table_pending) {
 #pragma unroll
             for (int k = 0; k < kLdsTable / kBlock; ++k) lds.table[tid + k * kBlock] = tab[k];
             table_pending = false;
         }
+        NMI_GRID_STAMP(2);  // this wavefront's share of the pixels done
         __syncthreads();  // B1
+        NMI_GRID_STAMP(3);
         if (a.phase_mask & 2) decode_phase<kZero0>(lds, par, a, wave, lane);
         __syncthreads();  // B2
+        NMI_GRID_STAMP(4);
         if (kOptimistic && (a.phase_mask & 3) == 3 && lds.total[par] != (uint32_t)a.npix) {
             // Some counter wrapped (workgroup-uniform, rare).  This candidate and, since the same frame and renders
             // come back, all later ones of this workgroup are scored on the exact path in the cold loop below.
@@ -717,6 +744,10 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void NMI_GRID_KERNEL_NAME(GridAr
                 lds.side_key[par][l] = lds.side_cnt[par][l] = 0;
             }
         }
+        NMI_GRID_STAMP(5);  // score committed (wavefront 0)
+#ifdef NMI_GRID_KERNEL_STAMPED
+        stamp_on = false;
+#endif
     }
 
     if (kOptimistic && exact_from >= 0) {
@@ -729,11 +760,23 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void NMI_GRID_KERNEL_NAME(GridAr
     }
 
     if (wave == 0 && !(a.phase_mask & 16)) {  // bit 4: timing experiment without the protocol (no result)
-        finish_search(a, lane, prev_key);
+        finish_search(a, lane, prev_key, gridDim.x);
     }
+#ifdef NMI_GRID_KERNEL_STAMPED
+    stamp_on = true;
+#endif
+    NMI_GRID_STAMP(6);
 }
 
-#ifdef NMI_GRID_KERNEL_GATED
+#if defined(NMI_GRID_KERNEL_STAMPED)
+// tools only: 256 bins, background rule on, default histogram variant
+hipError_t launch_grid_stamped(const GridArgs &a, int workgroups, hipStream_t stream)
+{
+    if (a.hist_variant != 3 || a.shift != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((nmi_grid_kernel_stamped<true, false, 3>), dim3(workgroups), dim3(kBlock), 0, stream, a);
+    return hipGetLastError();
+}
+#elif defined(NMI_GRID_KERNEL_GATED)
 // The fallback launch behind launch_fewlevels: 256 bins, default histogram variant.
 hipError_t launch_grid_gated(const GridArgs &a, int workgroups, bool use_bg, hipStream_t stream)
 {
@@ -907,7 +950,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_grid_kernel_ws(GridArgs
             if (k < n && (a.phase_mask & 1)) {
                 const int w = p / a.S_local, s = p - w * a.S_local;
                 histogram_phase<true, SHIFTED, 2, kHalf, false>(lds, 0, a, a.render_stack + (size_t)s * a.npix,
-                                                         a.warp_stack + (size_t)w * a.npix, tid);
+                                                         a.warp_stack + (size_t)w * a.npix, tid, 0, a.npix >> 4);
             }
         } else if (k > 0 && (a.phase_mask & 2)) {
             decode_from_scratch(lds, a, slab0 + ((k - 1) & 1) * kWords, dwave, lane);
@@ -1011,6 +1054,7 @@ hipError_t launch_grid(const GridArgs &a, int workgroups, bool use_bg, hipStream
     switch (a.hist_variant) {
     case 1: launch_hist<1>(a, grid, block, use_bg, stream); break;
     case 3:
+        if (a.dbg_stamps && use_bg && a.shift == 0) return launch_grid_stamped(a, workgroups, stream);  // tools/grid_stamps.py
         // The wrap detector of HIST = 3 needs the expected pixel count: W*H with BG on, and with BG off at 256 bins (the
         // kernel then counts every pixel and clears row / column 0 afterwards); BG off with fewer bins takes the exact path.
         if (use_bg || a.shift == 0)
@@ -1052,6 +1096,7 @@ bool ablation_variants_built()
 int grid_kernel_lds_bytes() { return (int)sizeof(Lds); }
 size_t grid_kernel_scratch_bytes(int workgroups) { return (size_t)workgroups * 2 * kWords * sizeof(uint32_t); }
 
-#endif  // !NMI_GRID_KERNEL_GATED
+#endif  // primary translation unit
+#endif  // !NMI_KERNELS_DEVICE_ONLY
 
 }  // namespace nmi

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(lib):
     raw = C.CDLL(capi.library_path())
     for name in declared_symbols():
         assert hasattr(raw, name), f"libnmi_hip.so does not export {name}"
-    assert lib.nmi_abi_version() == 1
+    assert lib.nmi_abi_version() == 2
 
 
 def test_params_default_match_reference_macros(lib):

@@ -38,7 +38,8 @@ def dev(a):
 # leaves compute units idle), 0 the one-workgroup-per-candidate kernel only, 8 / 4 / 2 forced.  Tests that take this
 # fixture run once per mode; results must be identical bit for bit.
 # A tuple (8, P) additionally forces P pixel ranges per row part (NMI_OPT_SPLIT_PIXELS); plain 8 / 4 / 2 run without them.
-@pytest.fixture(params=[-1, 0, (8, 4), (8, 2), (4, 2), 8, 4, 2],
+# (1, P): no row parts, P pixel ranges per candidate -- nmi_pix_kernel, the form of mid-size grids (csrc/nmi_pix_kernel.hip).
+@pytest.fixture(params=[-1, 0, (8, 4), (8, 2), (4, 2), 8, 4, 2, (1, 2), (1, 3), (1, 4)],
                 ids=lambda m: {-1: "auto", 0: "nosplit"}.get(m, f"split{m[0]}x{m[1]}" if isinstance(m, tuple) else f"split{m}"))
 def split_mode(request, nmi):
     from orbslam2_nmi_amd import capi
