@@ -136,6 +136,7 @@ static int next_split_epoch(nmi_ctx *ctx, uint32_t *epoch)
     uint32_t e = ctx->split_epoch + 1;
     if ((e & 0xFFFFu) == 0) {
         if (ctx->d_blocks) NMI_HIP_TRY(ctx, hipMemsetAsync(ctx->d_blocks, 0, ctx->blocks_bytes, ctx->stream));
+        if (ctx->d_pix_blocks) NMI_HIP_TRY(ctx, hipMemsetAsync(ctx->d_pix_blocks, 0, ctx->pix_blocks_bytes, ctx->stream));  // (its tags: 31 bits)
         if (e == 0 && ctx->d_slabs) NMI_HIP_TRY(ctx, hipMemsetAsync(ctx->d_slabs, 0, (size_t)ctx->slab_cap * sizeof(nmi::SplitSlab), ctx->stream));
         ++e;
     }
@@ -156,6 +157,23 @@ static int ensure_slabs(nmi_ctx *ctx, int n)
     NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_slabs, (size_t)cap * sizeof(nmi::SplitSlab)));
     NMI_HIP_TRY(ctx, hipMemsetAsync(ctx->d_slabs, 0, (size_t)cap * sizeof(nmi::SplitSlab), ctx->stream));  // epoch 0 = never written
     ctx->slab_cap = cap;
+    return NMI_OK;
+}
+
+// nmi_pix_kernel's hand-off blocks: a buffer of their own -- the row-split kernel tags its granules with 16 bits in the top of
+// an 8-byte word, which a packed counter of the other kernel's layout can equal.
+static int ensure_pix_blocks(nmi_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->pix_blocks_bytes) return NMI_OK;
+    if (ctx->d_pix_blocks) {
+        NMI_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        NMI_HIP_TRY(ctx, hipFree(ctx->d_pix_blocks));
+        ctx->d_pix_blocks = nullptr;
+        ctx->pix_blocks_bytes = 0;
+    }
+    NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_pix_blocks, bytes));
+    NMI_HIP_TRY(ctx, hipMemsetAsync(ctx->d_pix_blocks, 0, bytes, ctx->stream));  // tag 0 = never written
+    ctx->pix_blocks_bytes = bytes;
     return NMI_OK;
 }
 
@@ -290,14 +308,14 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
         a.split_error = ctx->d_split_error;
         workgroups = nmi::split_workgroups((int)total, parts, pix_parts);
     } else if (pix) {
-        int rs = ensure_blocks(ctx, nmi::pix_block_bytes((int)total, pix));
+        int rs = ensure_pix_blocks(ctx, nmi::pix_block_bytes((int)total, pix));
         if (rs == NMI_OK) rs = next_split_epoch(ctx, &a.epoch);
         if (rs == NMI_OK && !ctx->d_pix_timeouts) {
             NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_pix_timeouts, sizeof(uint32_t)));
             NMI_HIP_TRY(ctx, hipMemsetAsync(ctx->d_pix_timeouts, 0, sizeof(uint32_t), ctx->stream));
         }
         if (rs != NMI_OK) return rs;
-        a.blocks = ctx->d_blocks;
+        a.blocks = ctx->d_pix_blocks;
         workgroups = (int)total * pix;
     } else if (ctx->xcd_tiling && total <= (1ll << 24)) {  // 4 B per candidate
         const int orc = ensure_order(ctx, S_local, Wn, &a.order);
@@ -337,9 +355,9 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     if (parts) {
         NMI_HIP_TRY(ctx, nmi::launch_split(a, parts, pix_parts, workgroups, p.use_bg != 0, ctx->stream));
     } else if (pix) {
-        // the owner's range: an equal share plus what it can add while its helpers' counters travel (NMI_OPT_PIX_OWNER_BIAS pixels)
-        const int64_t owner_px = ((int64_t)ctx->npix + (int64_t)(pix - 1) * ctx->pix_owner_bias) / pix;
-        NMI_HIP_TRY(ctx, nmi::launch_pix(a, pix, (int)((owner_px < ctx->npix ? owner_px : ctx->npix) >> 4), p.use_bg != 0, nullptr, ctx->d_pix_timeouts, ctx->stream));
+        // the owner's share: an equal one plus what it can add while its helpers' counters travel (NMI_OPT_PIX_OWNER_BIAS pixels)
+        const double owner_px = ((double)ctx->npix + (double)(pix - 1) * ctx->pix_owner_bias) / pix;
+        NMI_HIP_TRY(ctx, nmi::launch_pix(a, pix, owner_px < ctx->npix ? owner_px / ctx->npix : 1.0, p.use_bg != 0, nullptr, ctx->d_pix_timeouts, ctx->stream));
     } else if (few) {
         NMI_HIP_TRY(ctx, nmi::launch_fewlevels(a, ctx->d_rank_stacks, ctx->d_rank_stacks + (size_t)S_local * ctx->npix, workgroups,
                                                p.use_bg != 0, ctx->stream));
@@ -370,15 +388,18 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
 bool split_launch_failed(nmi_ctx *ctx, int parts, uint32_t epoch)
 {
     if (!parts) return false;
-    uint32_t *word = ctx->h_split_error + (epoch & 15u);
+    uint32_t *word = ctx->h_split_error + (epoch % nmi::kSplitRing);
     if (__atomic_load_n(word, __ATOMIC_ACQUIRE) != epoch) {
-        ctx->split_backoff = nmi_ctx::kSplitBackoffMin;  // a split launch that went through: the short cooldown is re-armed
+        // a split launch that went through re-arms the short cooldown -- if it was issued AFTER the last pause was set: a sibling
+        // of the failed launch (same nmi_eval_pairs batch, stream tickets already in flight) says nothing about the retry
+        if ((int32_t)(epoch - ctx->split_cooldown_epoch) > 0) ctx->split_backoff = nmi_ctx::kSplitBackoffMin;
         return false;
     }
     (void)hipStreamSynchronize(ctx->stream);
     __atomic_store_n(word, 0u, __ATOMIC_RELEASE);
     ++ctx->split_timeouts;
     ctx->split_cooldown = ctx->split_backoff;
+    ctx->split_cooldown_epoch = ctx->split_epoch;
     if (ctx->split_backoff < nmi_ctx::kSplitBackoffMax) ctx->split_backoff *= 2;
     return true;
 }
@@ -581,9 +602,9 @@ int nmi_create(const nmi_params *params, nmi_ctx **out_ctx)
         hipSuccess)
         return fail(e, "hipHostMalloc(score mailbox)");
     memset(ctx->score_mailbox, 0, 2 * sizeof(unsigned long long));
-    if ((e = hipHostMalloc((void **)&ctx->h_split_error, 64, hipHostMallocCoherent | hipHostMallocMapped)) != hipSuccess)
+    if ((e = hipHostMalloc((void **)&ctx->h_split_error, nmi::kSplitRing * sizeof(uint32_t), hipHostMallocCoherent | hipHostMallocMapped)) != hipSuccess)
         return fail(e, "hipHostMalloc(split error)");
-    memset(ctx->h_split_error, 0, 64);
+    memset(ctx->h_split_error, 0, nmi::kSplitRing * sizeof(uint32_t));
     if ((e = hipHostGetDevicePointer((void **)&ctx->d_split_error, ctx->h_split_error, 0)) != hipSuccess)
         return fail(e, "hipHostGetDevicePointer(split error)");
     if ((e = hipHostMalloc((void **)&ctx->h_key, sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
@@ -625,6 +646,7 @@ int nmi_destroy(nmi_ctx *ctx)
     if (ctx->d_pair_scores) (void)hipFree(ctx->d_pair_scores);
     if (ctx->d_blocks) (void)hipFree(ctx->d_blocks);
     if (ctx->d_pix_timeouts) (void)hipFree(ctx->d_pix_timeouts);
+    if (ctx->d_pix_blocks) (void)hipFree(ctx->d_pix_blocks);
     if (ctx->h_split_error) (void)hipHostFree(ctx->h_split_error);
     if (ctx->level_post) (void)hipHostFree(ctx->level_post);
     if (ctx->d_plan) (void)hipFree(ctx->d_plan);
@@ -958,12 +980,20 @@ int nmi_eval_pairs(nmi_ctx *ctx, const uint8_t *const *h_renders, const uint8_t 
     if (n == 0) return NMI_OK;
     DeviceGuard guard(ctx->device);
     // launches of at most compute_units / 4 pairs (4 row parts each); small batches get more parts per pair
-    const int min_parts = ctx->split_mode > 0 ? ctx->split_mode : 4;
+    const int min_parts = ctx->split_mode > 1 ? ctx->split_mode : 4;
     const int cus = ctx->workgroups > 0 && ctx->workgroups < ctx->compute_units ? ctx->workgroups : ctx->compute_units;
     const int per_launch = cus / min_parts > 0 ? ((cus / min_parts) & ~7) > 0 ? (cus / min_parts) & ~7 : 1 : 1;
     // Decided BEFORE anything is launched: does a split form exist for every chunk of this batch (none does with
     // NMI_OPT_WORKGROUPS below 16, with NMI_OPT_SPLIT 0, or while the split forms are paused after a timeout)?
-    bool split_ok = ctx->hist_variant == 3 && ctx->split_mode != 0 && ctx->split_cooldown == 0;
+    if ((int64_t)n > (int64_t)per_launch * 128) {  // the timeout ring answers for at most kSplitRing launches in flight
+        for (int off = 0; off < n; off += per_launch * 128) {
+            const int m = n - off < per_launch * 128 ? n - off : per_launch * 128;
+            const int rc = nmi_eval_pairs(ctx, h_renders + off, h_warps + off, m, h_scores + off);
+            if (rc != NMI_OK) return rc;
+        }
+        return NMI_OK;
+    }
+    bool split_ok = ctx->hist_variant == 3 && ctx->split_mode != 0 && ctx->split_mode != 1 && ctx->split_cooldown == 0;
     for (int off = 0; split_ok && off < n; off += per_launch) {
         int parts = 0, pix = 1;
         choose_split(ctx, n - off < per_launch ? n - off : per_launch, ctx->workgroups > 0 ? ctx->workgroups : ctx->compute_units, &parts, &pix);

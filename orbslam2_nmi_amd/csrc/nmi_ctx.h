@@ -54,6 +54,7 @@ struct nmi_ctx {
     uint32_t split_timeouts = 0;           // timeouts seen so far
     uint32_t split_cooldown = 0;           // small-grid launches still to go through nmi_grid_kernel
     uint32_t split_backoff = kSplitBackoffMin;  // cooldown the next timeout starts
+    uint32_t split_cooldown_epoch = 0;     // newest split epoch issued when the last cooldown was set: only launches after it re-arm the short one
     static constexpr uint32_t kSplitBackoffMin = 16, kSplitBackoffMax = 4096;
     int result_path = 1;                   // 1 mailbox spin (default), 0 hipMemcpyAsync + stream sync
     bool posted = false;                   // the most recent launch posts to the mailbox
@@ -78,8 +79,10 @@ struct nmi_ctx {
     int slab_cap = 0;
     unsigned long long *d_blocks = nullptr;  // counter blocks (granules) of the split kernel's pixel parts
     uint32_t split_epoch = 0;             // tag of the latest split launch
-    uint32_t *h_split_error = nullptr, *d_split_error = nullptr;  // pinned ring [16]: word (epoch & 15) = epoch of a launch whose hand-off timed out
+    uint32_t *h_split_error = nullptr, *d_split_error = nullptr;  // pinned ring [nmi::kSplitRing]: word (epoch % kSplitRing) = epoch of a launch whose hand-off timed out
     size_t blocks_bytes = 0;
+    unsigned long long *d_pix_blocks = nullptr;  // hand-off blocks of nmi_pix_kernel (mid-size grids)
+    size_t pix_blocks_bytes = 0;
     // nmi_eval_pairs: pointer tables [2][pairs_cap] in pinned host memory (renders, then warps) + device scores
     const uint8_t **h_pair_table = nullptr, **d_pair_table = nullptr;
     float *d_pair_scores = nullptr;

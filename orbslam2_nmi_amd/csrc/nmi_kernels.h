@@ -36,6 +36,10 @@ struct LevelPlan {
                                          // the verdict CHANGES (a store to host memory holds the kernel's end back by a PCIe trip)
 };
 
+// Split-kernel timeouts are reported per launch through a ring of pinned words indexed by the launch's epoch: it must be longer
+// than the number of checked split launches that can be in flight (a stream of depth <= 64; an nmi_eval_pairs batch is cut to 128).
+constexpr uint32_t kSplitRing = 256;
+
 struct GridArgs {
     const uint8_t *render_stack;  // [S_local][H][W]
     const uint8_t *warp_stack;    // [Wn][H][W]
@@ -75,7 +79,7 @@ struct GridArgs {
     struct SplitSlab *slabs;        // split kernel: one hand-off slab per candidate (see nmi_split_kernel.hip)
     unsigned long long *blocks;     // split kernel with pixel parts: [candidate][row part][pixel part] blocks of 24+24+16-bit granules
     uint32_t epoch;                 // split kernel: this launch's tag (never 0; its low 16 bits never 0)
-    uint32_t *split_error;          // pinned host words [16]: a launch whose hand-off timed out stores its epoch into word epoch & 15
+    uint32_t *split_error;          // pinned host words [kSplitRing]: a launch whose hand-off timed out stores its epoch into word epoch % kSplitRing
     unsigned long long *dbg_stamps; // tools only (NMI_OPT_STAMPS): [workgroup][8] wall_clock64 stamps at phase boundaries
     uint32_t *dbg_joint, *dbg_h1, *dbg_h2;
     float *dbg_sums;
@@ -133,8 +137,8 @@ inline size_t split_block_bytes_per_candidate(int pix_parts) { return (size_t)pi
 // pair's pixels into a whole packed joint histogram; the helpers' histograms travel to the candidate's owner through
 // a.blocks (pix_block_bytes, zero when allocated; tag from a.epoch + *replay).  *timeouts counts candidates whose owner
 // gave up waiting and scored them alone (the launch heals itself).  Needs a.vec_ok, a.order == nullptr, a.epoch != 0.
-// owner_chunks: 16-pixel chunks of the owner's own range (the helpers share the rest).
-hipError_t launch_pix(const GridArgs &a, int pix_parts, int owner_chunks, bool use_bg, const uint32_t *replay, uint32_t *timeouts, hipStream_t stream);
+// owner_share: fraction of the pair's pixels the owner adds itself (the helpers share the rest equally).
+hipError_t launch_pix(const GridArgs &a, int pix_parts, double owner_share, bool use_bg, const uint32_t *replay, uint32_t *timeouts, hipStream_t stream);
 size_t pix_block_bytes(int candidates, int pix_parts);
 int pix_max_ranges();
 int grid_kernel_lds_bytes();

@@ -30,6 +30,7 @@
 //     replayed from a captured graph with frozen arguments (bumped by the graph's first node), absent otherwise.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #define NMI_KERNELS_DEVICE_ONLY 1
 #include "nmi_kernels.hip"  // Lds, histogram_phase, decode_phase, final_phase, finish_search, exact_candidate
@@ -58,11 +59,101 @@ struct PixHeader {
     uint32_t pad[16];
 };
 static_assert(sizeof(PixHeader) == 2048 + 128 && sizeof(PixHeader) % 128 == 0, "whole lines");
+
 constexpr size_t kPixBlockBytes = sizeof(PixHeader) + (size_t)kWords * sizeof(uint32_t);
 constexpr int kAuxSc1 = 16;  // cache-policy bits of the raw buffer intrinsics: sc1 (write-through store / L1-bypassing load)
 constexpr int kMaxRanges = 5;  // a wave's 64 lanes poll 16 granules of each of at most 4 helpers
 
 constexpr unsigned long long kPixTimeoutTicks = 200000ull;  // 2 ms of the 100 MHz clock; a hand-off takes microseconds
+
+// Which pixels a workgroup adds.  The pair is cut into PIECES of 64 chunks of 16 pixels (what one wavefront loads at once: 1.6
+// rows of a 640-pixel-wide frame) and the pieces are DEALT to the candidate's workgroups rather than cut into P contiguous
+// ranges: flat regions (render background, the warped frame's border) and busy ones cost different time per pixel and sit in
+// different parts of the frame -- with contiguous thirds the range at the bottom of the benchmark's frames took 7.9 us against
+// 6.2 for the middle one, up to 10.4, and a candidate is as slow as its slowest helper.  Dealing with period L = own + (P - 1) * hlp
+// pieces: the owner takes the first `own` pieces of every period, helper h the `hlp` pieces from own + (h - 1) * hlp on; own / L
+// is the owner's share (the host's choice, NMI_OPT_PIX_OWNER_BIAS).  A workgroup's i-th piece is piece
+// (i / cnt) * L + off + i % cnt of the frame; wavefront w takes i = 16 * iteration + w: scalar arithmetic only.
+struct Deal {
+    int L, off, cnt;      // period, this workgroup's first piece in a period, its pieces per period
+    uint32_t magic;       // ceil(2^32 / cnt): i / cnt = umulhi(i, magic) (exact far beyond the 2^14 pieces of a 2^24-pixel frame)
+    int n;                // pieces of this workgroup in the whole frame
+};
+// The dealing pattern of a launch, made by the host (launch_pix): the kernel does no division.
+struct DealArgs {
+    int own, hlp;                    // pieces per period of the owner / of each helper
+    uint32_t own_magic, hlp_magic;   // ceil(2^32 / own), ceil(2^32 / hlp) (unused when the count is 1)
+    int periods, rest;               // pieces of the frame = periods * L + rest, rest < L
+    uint32_t total_magic;            // ceil(2^32 / candidates) (0 for one candidate): block -> (range, candidate)
+};
+__device__ __forceinline__ Deal make_deal(const DealArgs &g, int P, int q)
+{
+    Deal d;
+    d.L = g.own + (P - 1) * g.hlp;
+    d.off = q == 0 ? 0 : g.own + (q - 1) * g.hlp;
+    d.cnt = q == 0 ? g.own : g.hlp;
+    d.magic = q == 0 ? g.own_magic : g.hlp_magic;
+    d.n = g.periods * d.cnt + min(max(g.rest - d.off, 0), d.cnt);
+    return d;
+}
+
+template <bool SHIFTED>
+__device__ __forceinline__ void histogram_dealt(Lds &lds, const GridArgs &a, const uint8_t *__restrict__ render, const uint8_t *__restrict__ warped,
+                                                int wave, int lane, const Deal &d)
+{
+    const int nchunks = a.npix >> 4, last = nchunks - 1;
+    auto ldw = [&](int c) { return *reinterpret_cast<const uint4 *>(warped + ((uint32_t)min(c, last) << 4)); };
+    auto ldr = [&](int c) {  // NMI.cu:82: row y of the frame meets row H-1-y of a bottom-up render (histogram_phase)
+        c = min(c, last);
+        const int y = (int)__umulhi((uint32_t)c, a.cpr_magic);
+        return *reinterpret_cast<const uint4 *>(render + ((uint32_t)(__mul24(y, a.flip_row) + c + a.flip_base) << 4));
+    };
+    // chunk of this lane in the workgroup's iteration `it`; beyond the workgroup's pieces: some chunk >= nchunks (not added)
+    auto chunk_of = [&](int it) {
+        const int i = it * kWaves + wave;  // wavefront-uniform
+        const int g = d.cnt > 1 ? (int)__umulhi((uint32_t)i, d.magic) : i;
+        const int t = g * d.L + d.off + (i - g * d.cnt);
+        return i < d.n ? (t << 6) + lane : 0x7FFFFFC0;
+    };
+    const int iters = (d.n + kWaves - 1) / kWaves;  // workgroup-uniform
+    if (iters <= 0) return;
+    const bool try_flat = !(a.phase_mask & 4);
+    int resume = -1;
+    int c = chunk_of(0);
+    uint4 wa = ldw(c), ra = ldr(c), wb, rb;
+    for (int it = 0; it < iters; it += 2) {
+        const int cb = chunk_of(it + 1);
+        wb = ldw(cb);
+        rb = ldr(cb);
+        if (__builtin_expect(flat_hint(ra, wa), 0)) {
+            resume = it;
+            break;
+        }
+        if (c < nchunks) add_chunk<true, SHIFTED, 2, false>(lds, 0, ra, wa, a.shift, false);
+        c = chunk_of(it + 2);
+        wa = ldw(c);
+        ra = ldr(c);
+        if (__builtin_expect(flat_hint(rb, wb), 0)) {
+            resume = it + 1;
+            break;
+        }
+        if (cb < nchunks) add_chunk<true, SHIFTED, 2, false>(lds, 0, rb, wb, a.shift, false);
+    }
+    if (resume >= 0) {
+        // careful loop: same adds, flat chunks folded (fold_flat_chunk); one chunk of prefetch
+        int cc = chunk_of(resume);
+        uint4 wc = ldw(cc), rc = ldr(cc);
+#pragma unroll 1
+        for (int it = resume; it < iters; ++it) {
+            const int cn = chunk_of(it + 1);
+            const uint4 wn = ldw(cn), rn = ldr(cn);
+            if (cc < nchunks) add_chunk<true, SHIFTED, 2, true>(lds, 0, rc, wc, a.shift, try_flat);
+            wc = wn;
+            rc = rn;
+            cc = cn;
+        }
+    }
+}
 
 // LDS word k (0..7) of decode lane (i, r = DPP row, o = r & 1) in joint row d1: decode_phase's ownership (nmi_kernels.hip)
 __device__ __forceinline__ uint32_t decode_word(int d1, int i, int o, int k)
@@ -175,7 +266,7 @@ size_t pix_block_bytes(int candidates, int pix_parts) { return (size_t)candidate
 int pix_max_ranges() { return kMaxRanges; }
 
 template <bool ZERO0, bool SHIFTED>
-__global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_pix_kernel(GridArgs a, int P, int owner_chunks, const uint32_t *replay, uint32_t *timeouts)
+__global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_pix_kernel(GridArgs a, int P, DealArgs dealing, const uint32_t *replay, uint32_t *timeouts)
 {
     __shared__ Lds lds;
     const int tid = threadIdx.x;
@@ -190,7 +281,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_pix_kernel(GridArgs a, 
     const int total = a.S_local * a.Wn;
     const int helpers = total * (P - 1);
     const int b = (int)blockIdx.x;
-    const int q = b < helpers ? 1 + b / total : 0;
+    const int q = b < helpers ? 1 + (total > 1 ? (int)__umulhi((uint32_t)b, dealing.total_magic) : b) : 0;
     const int p = b < helpers ? b - (q - 1) * total : b - helpers;
     const bool owner = q == 0;
     const int w = p / a.S_local, s = p - w * a.S_local;
@@ -217,16 +308,12 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_pix_kernel(GridArgs a, 
     if (tid < 2) lds.ovf_n[tid] = lds.total[tid] = 0;
     if (tid < 2 * kSide) (&lds.side_key[0][0])[tid] = (&lds.side_cnt[0][0])[tid] = 0;
     if (tid == 0) lds.fallback = 0;
+    // This workgroup's pixels (the host sends only 16-byte-path geometries here).  The owner's share is the larger one: its
+    // helpers' counters need a few microseconds to reach it, which it spends adding pixels.
+    const Deal deal = make_deal(dealing, P, q);
     __syncthreads();
     stamp(1);
-
-    // This workgroup's pixel range, in 16-pixel chunks (the host sends only 16-byte-path geometries here).  The owner's range
-    // is the longer one: its helpers' counters need a few microseconds to reach it, which it spends adding pixels.
-    const int nchunks = a.npix >> 4;
-    const int oc = min(max(owner_chunks, 0), nchunks);
-    const int per = (nchunks - oc + P - 2) / (P - 1);
-    const int c0 = owner ? 0 : min(oc + (q - 1) * per, nchunks), c1 = owner ? oc : min(c0 + per, nchunks);
-    histogram_phase<true, SHIFTED, 2, kBlock>(lds, 0, a, render, warped, tid, c0, c1);
+    histogram_dealt<SHIFTED>(lds, a, render, warped, wave, lane, deal);
 
     char *const blocks = reinterpret_cast<char *>(a.blocks) + (size_t)p * (size_t)(P - 1) * kPixBlockBytes;
     if (!owner) {
@@ -357,19 +444,38 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_pix_kernel(GridArgs a, 
 }
 
 // One launch of total * pix_parts workgroups.  Needs the 16-byte path (a.vec_ok), 256 bins or the background rule on, and
-// a.blocks of pix_block_bytes(total, pix_parts), zero when allocated.  owner_chunks: 16-pixel chunks of the owner's range.
-hipError_t launch_pix(const GridArgs &a, int pix_parts, int owner_chunks, bool use_bg, const uint32_t *replay, uint32_t *timeouts, hipStream_t stream)
+// a.blocks of pix_block_bytes(total, pix_parts), zero when allocated.  owner_share: the fraction of the pair's pixels the
+// owner adds itself (1 / pix_parts: equal shares).
+hipError_t launch_pix(const GridArgs &a, int pix_parts, double owner_share, bool use_bg, const uint32_t *replay, uint32_t *timeouts, hipStream_t stream)
 {
     const long long total = (long long)a.S_local * a.Wn;
     if (pix_parts < 2 || pix_parts > kMaxRanges || total <= 0 || total * pix_parts > 0x7FFFFFFFll) return hipErrorInvalidValue;
     if (!a.vec_ok || !a.blocks || a.hist_variant != 3 || (a.shift != 0 && !use_bg) || a.order) return hipErrorInvalidValue;
+    // the dealing pattern: own : hlp pieces per period, the closest to the wanted share among periods of at most 48 pieces
+    int own = 1, hlp = 1;
+    {
+        const double f = owner_share < 0.02 ? 0.02 : (owner_share > 0.98 ? 0.98 : owner_share);
+        double best = 2.0;
+        for (int b = 1; b <= 12; ++b) {
+            int o = (int)(f / (1.0 - f) * (pix_parts - 1) * b + 0.5);
+            o = o < 1 ? 1 : o;
+            if (o + (pix_parts - 1) * b > 48) break;
+            const double err = fabs((double)o / (o + (pix_parts - 1) * b) - f);
+            static const double kCloser = getenv("NMI_PIX_CLOSER") ? atof(getenv("NMI_PIX_CLOSER")) : 0.03;  // (experiments)
+            if (err < best - kCloser) best = err, own = o, hlp = b;  // a longer period has to be clearly closer: dealt in runs of 5 pieces
+                                                                      // (8 rows) one helper was 16 % slower than the other on the benchmark's frames
+        }
+    }
+    auto magic = [](int d) { return d > 1 ? (uint32_t)((0x100000000ull + (uint32_t)d - 1) / (uint32_t)d) : 0u; };
+    const int pieces = ((a.npix >> 4) + 63) >> 6, L = own + (pix_parts - 1) * hlp;
+    const DealArgs g{own, hlp, magic(own), magic(hlp), pieces / L, pieces % L, magic((int)total)};
     const dim3 grid((unsigned)(total * pix_parts)), block(kBlock);
     if (a.shift != 0)
-        hipLaunchKernelGGL((nmi_pix_kernel<false, true>), grid, block, 0, stream, a, pix_parts, owner_chunks, replay, timeouts);
+        hipLaunchKernelGGL((nmi_pix_kernel<false, true>), grid, block, 0, stream, a, pix_parts, g, replay, timeouts);
     else if (use_bg)
-        hipLaunchKernelGGL((nmi_pix_kernel<false, false>), grid, block, 0, stream, a, pix_parts, owner_chunks, replay, timeouts);
+        hipLaunchKernelGGL((nmi_pix_kernel<false, false>), grid, block, 0, stream, a, pix_parts, g, replay, timeouts);
     else
-        hipLaunchKernelGGL((nmi_pix_kernel<true, false>), grid, block, 0, stream, a, pix_parts, owner_chunks, replay, timeouts);
+        hipLaunchKernelGGL((nmi_pix_kernel<true, false>), grid, block, 0, stream, a, pix_parts, g, replay, timeouts);
     return hipGetLastError();
 }
 

@@ -88,7 +88,7 @@ __device__ __forceinline__ unsigned long long load_granule(const unsigned long l
 __device__ __forceinline__ unsigned long long granule32(uint32_t payload, uint32_t epoch) { return (unsigned long long)payload | ((unsigned long long)epoch << 32); }
 // Every poll loop is bounded in real time: a legitimate hand-off arrives within ~5 us; after kTimeoutTicks of the 100 MHz
 // wall clock (2 ms) the waiter gives up.  (The clock is read every 16th unsuccessful poll only; kMaxPolls is the backstop
-// should the clock misbehave.)  The timeout is reported per launch: the launch's epoch goes into word (epoch & 15) of the
+// should the clock misbehave.)  The timeout is reported per launch: the launch's epoch goes into word (epoch % kSplitRing) of the
 // pinned error ring, so the host can tell WHICH of several launches in flight failed (nmi_capi.cpp, split_launch_failed).
 constexpr unsigned long long kTimeoutTicks = 200000ull;
 constexpr int kMaxPolls = 1 << 15;
@@ -109,7 +109,7 @@ struct PollGuard {
 };
 __device__ __forceinline__ void raise_timeout(const GridArgs &a)
 {
-    if (a.split_error) __hip_atomic_store(a.split_error + (a.epoch & 15u), a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.split_error) __hip_atomic_store(a.split_error + (a.epoch % kSplitRing), a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // 16 pixels of one lane, hot case (BG on, 256 bins).  xorpat holds (part * kRows) in every byte: after r ^= xorpat a pixel

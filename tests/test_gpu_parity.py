@@ -725,6 +725,38 @@ def test_stream_ticket_answers_for_its_own_split_timeout(nmi):
             assert st.wait(a) == exp[1][1:]
 
 
+def test_split_timeouts_sixteen_launches_apart_are_both_seen(nmi):
+    """the ring of per-launch timeout words had 16 entries indexed by epoch & 15 while a stream holds up to 64
+    tickets -- a timeout in launch e + 16 overwrote launch e's word, and ticket e returned the key of a timed-out search as
+    valid.  18 tickets in flight, the 1st and the 17th time out: both are noticed, redone, and answer with the oracle's winner."""
+    from oracle import binding as oc
+    from orbslam2_nmi_amd import capi, synthetic as sy
+    w, h, counts = 160, 120, (3, 1, 1)
+    K = sy.intrinsics(w, h)
+    B = sy.scene(w, h, 51)
+    F = sy.camera_frame(B, 52)
+    rs = [sy.render_stack(B, (2, 1, 1), shift_px=1 + i) for i in range(3)]
+    Ms = capi.warp_homographies(K, counts, (0.02, 0.02, 0.05))
+    with nmi.NmiContext(w, h, render_bottom_up=False) as ctx:
+        ws = ctx.warp_stack(dev(F), Ms)
+        wsh = ws.cpu().numpy()
+        with oc.rounded():
+            exp = [oc.search_grid(r, wsh, render_bottom_up=False) for r in rs]
+        hf = torch.from_numpy(F).pin_memory()
+        hr = [torch.from_numpy(r).pin_memory() for r in rs]
+        with nmi.NmiStream(ctx, 2, 3, depth=20) as st:
+            tickets = []
+            for i in range(18):
+                if i in (0, 16):
+                    ctx.set_option(ctx.OPT_PHASE_MASK, 3 | 512)
+                tickets.append(st.submit(hr[i % 3], hf, Ms) if i == 0 else st.submit(hr[i % 3]))
+                ctx.set_option(ctx.OPT_PHASE_MASK, 3)
+                assert ctx.split_status()["last_launch_parts"] == 8
+            for i, t in enumerate(tickets):
+                assert st.wait(t) == exp[i % 3][1:], i
+            assert ctx.split_status()["timeouts"] == 2
+
+
 def test_invalid_arguments_fail_loudly(nmi):
     with nmi.NmiContext(64, 48) as ctx:
         with pytest.raises(TypeError):
