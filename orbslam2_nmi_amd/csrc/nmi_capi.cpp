@@ -111,10 +111,10 @@ static void choose_split(const nmi_ctx *ctx, int64_t total, int cap, int *parts,
 }
 
 // Pixel ranges per candidate for nmi_pix_kernel (nmi_pix_kernel.hip), 0 = another kernel.  The owner of a candidate adds
-// its P - 1 helpers' histograms to its own (~1.3 us each), so P grows only while the histogram phase (21 us / P at 640x480)
-// shrinks faster: automatic choice 4 up to 64 candidates, 3 up to 85, 2 up to 128 (256 CUs); smaller grids keep the
-// row-split forms, larger ones have no CU to spare.  NMI_OPT_SPLIT 1 + NMI_OPT_SPLIT_PIXELS P forces P wherever it fits.
-static int choose_pix(const nmi_ctx *ctx, const nmi::GridArgs &a, int64_t total, int cap)
+// its P - 1 helpers' histograms to its own and waits for the slowest of them, so P grows only while the histogram phase
+// (21 us / P at 640x480) shrinks faster: automatic choice 3 up to 85 candidates, 2 up to 128 (256 CUs; measured, with 4 and
+// 5: profiles/r04_a/small_grid_time.txt); smaller grids keep the row-split forms, larger ones have no CU to spare.  NMI_OPT_SPLIT 1 + NMI_OPT_SPLIT_PIXELS P forces P wherever it fits.
+int choose_pix(const nmi_ctx *ctx, const nmi::GridArgs &a, int64_t total, int cap)
 {
     if (cap > ctx->compute_units) cap = ctx->compute_units;  // (an owner that waits for a CU starts a second round)
     if (ctx->hist_variant != 3 || !a.vec_ok || (ctx->shift != 0 && !ctx->params.use_bg) || ctx->pair_renders || total <= 0) return 0;
@@ -125,13 +125,28 @@ static int choose_pix(const nmi_ctx *ctx, const nmi::GridArgs &a, int64_t total,
     }
     if (ctx->split_mode != -1 || ctx->split_pixels != -1 || total <= 32 || total * 2 > cap) return 0;
     const int p = (int)(cap / total);
-    return p > 4 ? 4 : p;
+    return p > 3 ? 3 : p;
+}
+
+// the owner's share of a candidate's pixels: an equal one plus what it can add while its helpers' counters travel
+double pix_owner_share(const nmi_ctx *ctx, int pix)
+{
+    const double owner_px = ((double)ctx->npix + (double)(pix - 1) * ctx->pix_owner_bias) / pix;
+    return owner_px < ctx->npix ? owner_px / ctx->npix : 1.0;
+}
+
+int ensure_pix_timeouts(nmi_ctx *ctx)
+{
+    if (ctx->d_pix_timeouts) return NMI_OK;
+    NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_pix_timeouts, sizeof(uint32_t)));
+    NMI_HIP_TRY(ctx, hipMemsetAsync(ctx->d_pix_timeouts, 0, sizeof(uint32_t), ctx->stream));
+    return NMI_OK;
 }
 
 // Epoch of the next split launch.  Slab granules carry all 32 bits, block granules the low 16: neither may be 0 (the
 // cleared state), and whenever the low 16 bits wrap the blocks are cleared so that no granule older than 65535 launches
 // can show the current tag (the slabs likewise when all 32 bits wrap).
-static int next_split_epoch(nmi_ctx *ctx, uint32_t *epoch)
+int next_split_epoch(nmi_ctx *ctx, uint32_t *epoch)
 {
     uint32_t e = ctx->split_epoch + 1;
     if ((e & 0xFFFFu) == 0) {
@@ -310,10 +325,7 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     } else if (pix) {
         int rs = ensure_pix_blocks(ctx, nmi::pix_block_bytes((int)total, pix));
         if (rs == NMI_OK) rs = next_split_epoch(ctx, &a.epoch);
-        if (rs == NMI_OK && !ctx->d_pix_timeouts) {
-            NMI_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_pix_timeouts, sizeof(uint32_t)));
-            NMI_HIP_TRY(ctx, hipMemsetAsync(ctx->d_pix_timeouts, 0, sizeof(uint32_t), ctx->stream));
-        }
+        if (rs == NMI_OK) rs = ensure_pix_timeouts(ctx);
         if (rs != NMI_OK) return rs;
         a.blocks = ctx->d_pix_blocks;
         workgroups = (int)total * pix;
@@ -355,9 +367,7 @@ int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_o
     if (parts) {
         NMI_HIP_TRY(ctx, nmi::launch_split(a, parts, pix_parts, workgroups, p.use_bg != 0, ctx->stream));
     } else if (pix) {
-        // the owner's share: an equal one plus what it can add while its helpers' counters travel (NMI_OPT_PIX_OWNER_BIAS pixels)
-        const double owner_px = ((double)ctx->npix + (double)(pix - 1) * ctx->pix_owner_bias) / pix;
-        NMI_HIP_TRY(ctx, nmi::launch_pix(a, pix, owner_px < ctx->npix ? owner_px / ctx->npix : 1.0, p.use_bg != 0, nullptr, ctx->d_pix_timeouts, ctx->stream));
+        NMI_HIP_TRY(ctx, nmi::launch_pix(a, pix, pix_owner_share(ctx, pix), p.use_bg != 0, nullptr, ctx->d_pix_timeouts, ctx->stream));
     } else if (few) {
         NMI_HIP_TRY(ctx, nmi::launch_fewlevels(a, ctx->d_rank_stacks, ctx->d_rank_stacks + (size_t)S_local * ctx->npix, workgroups,
                                                p.use_bg != 0, ctx->stream));

@@ -38,7 +38,10 @@ struct nmi_level {
     float *d_ratings = nullptr;                 // [Wn][S] rating table of the latest replay
     unsigned long long *d_key = nullptr, *h_key = nullptr;
     unsigned int *d_done = nullptr;
-    uint32_t *d_epoch = nullptr;                // replay parity of the double-buffered anchors (fused point-cloud form)
+    uint32_t *d_epoch = nullptr;                // replays so far, bumped by the prep kernel: parity of the double-buffered anchors (fused
+                                                // point-cloud form), tag of the search kernel's hand-offs (nmi_pix_kernel)
+    unsigned long long *d_pix_blocks = nullptr; // nmi_pix_kernel's hand-off blocks when the level's grid is a mid-size one
+    int pix = 0;                                // pixel ranges per candidate of the captured search (0: nmi_grid_kernel)
     hipStream_t side = nullptr;                 // forked capture branch (warp)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipGraph_t graph = nullptr;
@@ -54,7 +57,7 @@ int nmi_level_destroy(nmi_level *lv)
     (void)hipStreamSynchronize(lv->ctx->stream);
     if (lv->exec) (void)hipGraphExecDestroy(lv->exec);
     if (lv->graph) (void)hipGraphDestroy(lv->graph);
-    void *dev[] = {lv->d_kept, lv->d_kept_count, lv->d_packed, lv->d_renders, lv->d_warps, lv->d_zbuf, lv->d_mvps, lv->d_coeffs, lv->d_order, lv->d_key, lv->d_done, lv->d_ratings, lv->d_epoch};
+    void *dev[] = {lv->d_kept, lv->d_kept_count, lv->d_packed, lv->d_renders, lv->d_warps, lv->d_zbuf, lv->d_mvps, lv->d_coeffs, lv->d_order, lv->d_key, lv->d_done, lv->d_ratings, lv->d_epoch, lv->d_pix_blocks};
     for (void *q : dev)
         if (q) (void)hipFree(q);
     void *host[] = {lv->h_mvps, lv->h_coeffs, lv->h_key};
@@ -130,6 +133,8 @@ static int level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_attr, i
     if (tex) {
         if (mesh_work_alloc(ctx, S, &lv->mesh) != NMI_OK) e = hipErrorOutOfMemory;
         if (e == hipSuccess && ensure_mesh_pairs(ctx, &lv->mesh, n_points) != NMI_OK) e = hipErrorOutOfMemory;
+        ok(hipMalloc((void **)&lv->d_epoch, sizeof(uint32_t)));
+        if (e == hipSuccess) ok(hipMemsetAsync(lv->d_epoch, 0, sizeof(uint32_t), ctx->stream));
     } else {
         // Anchors: two buffers when the level runs as one chain of kernels (the front kernel of replay k clears the buffer of
         // replay k + 1); the classic form keeps one and clears it in its prep node.
@@ -204,13 +209,25 @@ static int level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_attr, i
     a.phase_mask = 3;
     const int cap = ctx->workgroups > 0 ? ctx->workgroups : ctx->compute_units;
     const int workgroups = (int)(total < cap ? total : cap);
+    // Mid-size grids (the live strategy's collapsed levels, a rank's block of a sharded level): P workgroups per candidate
+    // (nmi_pix_kernel.hip).  Its hand-off tag = the epoch frozen into the graph + the replay count the prep kernel keeps.
+    lv->pix = e == hipSuccess ? choose_pix(ctx, a, total, cap) : 0;
+    if (lv->pix) {
+        const size_t bytes = nmi::pix_block_bytes((int)total, lv->pix);
+        ok(hipMalloc((void **)&lv->d_pix_blocks, bytes));
+        if (e == hipSuccess) ok(hipMemset(lv->d_pix_blocks, 0, bytes));
+        if (e == hipSuccess && (next_split_epoch(ctx, &a.epoch) != NMI_OK || ensure_pix_timeouts(ctx) != NMI_OK)) e = hipErrorOutOfMemory;
+        if (e == hipSuccess) ok(hipStreamSynchronize(ctx->stream));
+        a.blocks = lv->d_pix_blocks;
+        a.order = nullptr;
+    }
 
     hipStream_t st = ctx->stream;
     if (e == hipSuccess && ok(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal))) {
         // (mesh: nothing to clear -- the renderer leaves its work area clean)
         ok(nmi::launch_level_prep(hd_mvps, lv->d_mvps, S * 16 + nmi::kLevelMvpExtra, hd_coeffs, lv->d_coeffs, Wn * 9, lv->d_key, lv->d_zbuf,
                                   (tex || lv->fused_points) ? 0 : nmi::render_zbuf_words(S, p.width, p.height, lv->size), st,
-                                  lv->fused_points ? lv->d_epoch : nullptr, lv->fused_points ? lv->d_packed : nullptr, n_points,
+                                  lv->d_epoch, lv->fused_points ? lv->d_packed : nullptr, n_points,
                                   lv->fused_points ? hd_mvps + (size_t)S * 16 : nullptr, lv->d_kept, lv->d_kept_count));
         // One chain of kernels when the warp blocks can ride along with the render's first kernel (the usual case: frame rows
         // 16-byte aligned); otherwise the warp kernel runs on a forked branch beside the render.
@@ -232,7 +249,10 @@ static int level_create(nmi_ctx *ctx, const float *d_xyz, const float *d_attr, i
             ok(nmi::launch_render_points(d_xyz, d_red, n_points, lv->d_mvps, S, lv->d_zbuf, lv->d_renders, p.width, p.height, lv->size, st,
                                          /*clear_first=*/false));
         if (!fused) ok(hipStreamWaitEvent(st, lv->ev_join, 0));
-        ok(nmi::launch_grid(a, workgroups, true, st));
+        if (lv->pix)
+            ok(nmi::launch_pix(a, lv->pix, pix_owner_share(ctx, lv->pix), true, lv->d_epoch, ctx->d_pix_timeouts, st));
+        else
+            ok(nmi::launch_grid(a, workgroups, true, st));
         hipError_t ec = hipStreamEndCapture(st, &lv->graph);
         ok(ec);
     }

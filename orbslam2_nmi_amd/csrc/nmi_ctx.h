@@ -154,6 +154,12 @@ int rccl_allreduce_key(nmi_ctx *ctx, const unsigned long long *d_send, unsigned 
 int hip_fail(nmi_ctx *ctx, hipError_t e, const char *what);
 void build_order(int S, int Wn, int *order);
 int ensure_order(nmi_ctx *ctx, int S, int Wn, const int **d_order);
+// nmi_pix_kernel (mid-size grids): pixel ranges per candidate for a launch of `total` candidates on `cap` workgroups (0: another
+// kernel), the owner's share of the pixels, the next hand-off epoch, the context's counter of healed timeouts
+int choose_pix(const nmi_ctx *ctx, const nmi::GridArgs &a, int64_t total, int cap);
+double pix_owner_share(const nmi_ctx *ctx, int pix);
+int next_split_epoch(nmi_ctx *ctx, uint32_t *epoch);
+int ensure_pix_timeouts(nmi_ctx *ctx);
 int enqueue_grid(nmi_ctx *ctx, const uint8_t *render_stack, int S_local, int s_offset, int S_total, const uint8_t *warp_stack, int Wn,
                  float *d_ratings, unsigned long long *out_key, bool post, uint32_t *dbg_joint, uint32_t *dbg_h1, uint32_t *dbg_h2,
                  float *dbg_sums, int w_offset = 0, bool post_score = false);
