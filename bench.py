@@ -161,12 +161,12 @@ def rank_evidence(world, dist, local_device):
     reports it, the backend's name and every rank's device ordinal (gathered through that same backend)."""
     import torch
     if dist is None:
-        return {"rccl_ranks": 1, "backend": "none", "device_ordinals": [local_device]}
+        return {"collective_ranks": 1, "rccl": False, "backend": "none", "device_ordinals": [local_device]}
     backend = dist.get_backend()
     t = torch.zeros(world, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
     t[dist.get_rank()] = local_device + 1
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return {"rccl_ranks": dist.get_world_size(), "backend": "nccl (RCCL)" if backend == "nccl" else backend,
+    return {"collective_ranks": dist.get_world_size(), "rccl": backend == "nccl", "backend": "nccl (RCCL)" if backend == "nccl" else backend,
             "device_ordinals": [int(v) - 1 for v in t.cpu().tolist()]}
 
 
@@ -522,7 +522,13 @@ def main():
                     help="untimed searches for this long before the warm-up steps, to bring the device to its sustained clock (0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-call-site", action="store_true", help="skip the call_site key (examples/relocalize_demo as a child process)")
-    ap.add_argument("--blocking", action="store_true", help="latency mode: one blocking search per step")
+    ap.add_argument("--blocking", action="store_true", help="one blocking search per step (SURVEY.md 8d's definition): the default with one GPU")
+    ap.add_argument("--throughput", action="store_true",
+                    help="steps enqueued back to back, every winner read back and checked in the timed region: the default with N > 1; "
+                         "with one GPU it is measured as well and reported as throughput_evals_per_s")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="c2 / c3 / c4 with N > 1: weak = every rank scores a whole grid of its own renders (per-GPU work fixed); strong = "
+                         "ONE grid, its cells dealt to the ranks (sharding.grid_shard), total work fixed")
     ap.add_argument("--streams", type=int, default=1,
                     help="searches kept in flight in throughput mode (one context + stream each); 2 fills the idle CUs of the "
                          "85%%-full last round (+5%%) but makes per-launch durations overlap, so the default stays 1")
@@ -564,26 +570,42 @@ def main():
 
     rank, local_rank, world, dist = init_dist(args)
     nmi.load_library()
+    if args.blocking and args.throughput:
+        sys.exit("bench.py: --blocking and --throughput exclude each other")
+    # SURVEY.md 8(d) defines the metric on ONE blocking nmi_search_grid call including its 8-byte read-back: that is `value` on
+    # one GPU (the back-to-back figure goes beside it as throughput_evals_per_s).  N > 1 measures throughput and says so.
+    blocking_mode = args.blocking or (world == 1 and not args.throughput and dist is None)
+    strong = args.scaling == "strong" and world > 1
 
     # ---- synthetic inputs, resident in HBM before any timing ------------------------------------------
     # rank 0 holds the renders of the planted scene; other ranks render a different scene (their candidates score
     # lower), so the global winner must come out of the collective as rank 0's centre cell.
     wl = sy.workload(WIDTH, HEIGHT, S_PER_RANK, WN, seed=1234)
-    if rank > 0:
-        other = sy.scene(WIDTH, HEIGHT, 5000 + rank)
-        wl["render_stack"] = sy.render_stack(other, wl["s_counts"], bottom_up=True)
-    S_total = S_PER_RANK * world
-    s_offset = S_PER_RANK * rank
-    rs = torch.from_numpy(wl["render_stack"]).cuda()
-    ws = torch.from_numpy(wl["warp_stack"]).cuda()
-    w_c, s_c = divmod(wl["planted"], S_PER_RANK)
-    planted_global = w_c * S_total + s_c
+    from orbslam2_nmi_amd import sharding
+    if strong:
+        # ONE grid for all ranks: rank r scores the block sharding.grid_shard deals it (render axis; the warp axis when there
+        # are fewer renders than ranks), indices stay global, the winner comes out of the collective
+        s_offset, s_local, w_offset, w_local = sharding.grid_shard(S_PER_RANK, WN, rank, world)
+        S_total, WN_total = S_PER_RANK, WN
+        rs = torch.from_numpy(np.ascontiguousarray(wl["render_stack"][s_offset:s_offset + s_local])).cuda()
+        ws = torch.from_numpy(np.ascontiguousarray(wl["warp_stack"][w_offset:w_offset + w_local])).cuda()
+        planted_global = wl["planted"]
+    else:
+        if rank > 0:
+            other = sy.scene(WIDTH, HEIGHT, 5000 + rank)
+            wl["render_stack"] = sy.render_stack(other, wl["s_counts"], bottom_up=True)
+        S_total, WN_total = S_PER_RANK * world, WN
+        s_offset, s_local, w_offset, w_local = S_PER_RANK * rank, S_PER_RANK, 0, WN
+        rs = torch.from_numpy(wl["render_stack"]).cuda()
+        ws = torch.from_numpy(wl["warp_stack"]).cuda()
+        w_c, s_c = divmod(wl["planted"], S_PER_RANK)
+        planted_global = w_c * S_total + s_c
 
     # Throughput mode keeps --streams searches in flight, each on its own context and non-default stream: a 729-candidate
     # search is 2.85 rounds of the chip, so the workgroups of the next search fill the CUs that the last round (and the
     # launch / completion latency) of the previous one leaves idle.  Every stream carries its kernels, the collective's
     # dependency and the read-backs.  --blocking uses one stream.
-    n_streams = 1 if args.blocking else max(1, args.streams)
+    n_streams = 1 if blocking_mode else max(1, args.streams)
     torch.cuda.synchronize()
     streams = [torch.cuda.Stream() for _ in range(n_streams)]
     ctxs = []
@@ -603,8 +625,6 @@ def main():
                 c.set_option(c.OPT_WORKGROUPS, cus - 8)
     key = torch.zeros(1, dtype=torch.int64, device="cuda")
 
-    from orbslam2_nmi_amd import sharding
-
     # Steps are enqueued back to back (throughput mode): step i's kernel writes its packed winner to keys[i]; with N>1
     # the MAX all-reduce of the winners (8 bytes per step, --allreduce-bucket steps per message) is issued asynchronously
     # and overlaps the following kernels.  All winners are read back and checked inside the timed region.  --blocking times the latency-bound form instead
@@ -619,7 +639,9 @@ def main():
             if dist is None:
                 res = ctx.search_grid(rs, ws)
             else:
-                res = sharding.sharded_search(ctx, rs, s_offset, S_total, ws, key, dist)
+                ctx.search_grid_shard(rs, s_offset, S_total, ws, key_out=key, blocking=False, w_offset=w_offset, wn_total=WN_total)
+                sharding.allreduce_key(key, dist)
+                res = nmi.key_unpack(int(key.item()))
             if res[0] != planted_global:
                 sys.exit(f"rank {rank}: wrong winner {res} (expected index {planted_global})")
 
@@ -635,7 +657,7 @@ def main():
             slot = keys[i:i + 1]
             k = i % n_streams
             torch.cuda.set_stream(streams[k])
-            ctxs[k].search_grid_shard(rs, s_offset, S_total, ws, key_out=slot, blocking=False)
+            ctxs[k].search_grid_shard(rs, s_offset, S_total, ws, key_out=slot, blocking=False, w_offset=w_offset, wn_total=WN_total)
             if dist is not None and ((i + 1) % bucket == 0 or i == n - 1):
                 # The search's only exchange: MAX over ranks of the 8-byte packed winner.  The winners of `bucket`
                 # consecutive (independent) steps travel in one message: a per-step collective costs ~10 us of the
@@ -661,7 +683,7 @@ def main():
         if bad.size:
             sys.exit(f"rank {rank}: {bad.size} wrong winners, e.g. {nmi.key_unpack(int(bad[0]))} (expected index {planted_global})")
 
-    run = run_blocking if args.blocking else run_async
+    run = run_blocking if blocking_mode else run_async
 
     def sync_all():
         torch.cuda.synchronize()
@@ -692,22 +714,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # latency of one blocking call (kernel + 8-byte winner on the host), for the record
-    ctx.search_grid(rs, ws)
-    torch.cuda.synchronize()
-    tb = time.perf_counter()
-    for _ in range(50):
-        ctx.search_grid(rs, ws)
-    blocking_call_ms = (time.perf_counter() - tb) / 50 * 1e3
+    # the other mode, for the record: with one GPU the timed region above was blocking calls, so the back-to-back form is
+    # measured here over the same K steps (its HIP events give the kernel's average launch duration); otherwise 50 blocking calls
+    throughput_ms_per_step = None
+    if blocking_mode and world == 1 and dist is None:
+        run_async(min(args.warmup, 20))
+        torch.cuda.synchronize()
+        tt = time.perf_counter()
+        run_async(args.steps)
+        torch.cuda.synchronize()
+        throughput_ms_per_step = (time.perf_counter() - tt) / args.steps * 1e3
+        blocking_call_ms = elapsed / args.steps * 1e3
+    else:
+        ctx.search_grid_shard(rs, s_offset, S_total, ws, key_out=key, blocking=True, w_offset=w_offset, wn_total=WN_total)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for _ in range(50):
+            ctx.search_grid_shard(rs, s_offset, S_total, ws, key_out=key, blocking=True, w_offset=w_offset, wn_total=WN_total)
+        blocking_call_ms = (time.perf_counter() - tb) / 50 * 1e3
 
     # ---- dominant kernel: live HIP-event timing on the launch stream ----------------------------------
     ctx.set_profiling(True)
     durs = []
     for _ in range(min(args.steps, 100)):
-        if world == 1:
-            ctx.search_grid(rs, ws)
-        else:
-            ctx.search_grid_shard(rs, s_offset, S_total, ws, key_out=key, blocking=True)
+        ctx.search_grid_shard(rs, s_offset, S_total, ws, key_out=key, blocking=True, w_offset=w_offset, wn_total=WN_total)
         durs.append(ctx.last_kernel_ms())
     ctx.set_profiling(False)
     kernel_ms_exclusive = float(np.mean(durs))
@@ -715,7 +745,7 @@ def main():
     # after the last of the K back-to-back launches (one stream: the launches run one after the other, so this is the
     # kernel's duration plus the ~1 us hand-over between launches).  With several streams the launches overlap and a
     # per-launch duration is not defined: the exclusive figure (one launch at a time, events around it) is used.
-    if not args.blocking and n_streams == 1 and "events" in region:
+    if n_streams == 1 and "events" in region:
         e0, e1, n_timed = region["events"]
         kernel_ms = e0.elapsed_time(e1) / n_timed
     else:
@@ -723,19 +753,22 @@ def main():
 
     evidence = rank_evidence(world, dist, local_rank)
     if rank == 0:
-        evals_per_step = S_total * WN
-        per_launch_evals = S_PER_RANK * WN
+        evals_per_step = S_total * WN_total
+        per_launch_evals = s_local * w_local
+        pix = ctx.pix_status()["last_launch_ranges"]
         achieved = per_launch_evals * algorithmic_bytes_per_eval(WIDTH, HEIGHT) / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": f"pose-candidate NMI evals/sec ({WIDTH}x{HEIGHT}, 256 bins)" +
-                      (", one blocking nmi_search_grid call per step (SURVEY.md 8d)" if args.blocking else
+                      (", one blocking nmi_search_grid call per step incl. its 8-byte read-back (SURVEY.md 8d's definition)" if blocking_mode else
                        ", throughput mode: steps enqueued back to back, every winner read back and checked in the timed region") +
                       (f"; beside the W warm-up steps an untimed clock warm-up of clock_warmup_ms = {args.clock_warmup_ms:g} ms precedes the timed region"
                        if args.clock_warmup_ms > 0 else ""),
             "extra_warmup": "clock_warmup_ms",
             "value": evals_per_step * args.steps / elapsed,
-            # SURVEY.md 8(d) defines the metric on ONE blocking nmi_search_grid call including its 8-byte read-back:
+            # one blocking call of THIS rank's block incl. its 8-byte read-back (== value with one GPU and no --throughput)
             "blocking_call_evals_per_s": per_launch_evals / (blocking_call_ms * 1e-3),
+            "throughput_evals_per_s": (evals_per_step / (throughput_ms_per_step * 1e-3) if throughput_ms_per_step else
+                                       (None if blocking_mode else evals_per_step * args.steps / elapsed)),
             "unit": "evals/s",
             "n_gpus": world,
             **evidence,
@@ -743,28 +776,29 @@ def main():
             "warmup": args.warmup,
             "clock_warmup_ms": args.clock_warmup_ms,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "step_mode": "blocking call per step" if args.blocking else
+            "step_mode": "blocking call per step" if blocking_mode else
                          "steps enqueued back to back; every step's winner read back and checked inside the timed region",
             "blocking_call_ms": blocking_call_ms,
             "streams": n_streams,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "u8", "dtype_detail": "u8 pixels -> u32 histogram counts (integer, exact); f32 entropy terms and score",
             "data": "synthetic",
-            "config": {"workload": workload_name + ", 256-bin NMI (SUC), render axis sharded by rank",
-                       "width": WIDTH, "height": HEIGHT, "renders_per_gpu": S_PER_RANK, "warps": WN,
-                       "candidates_total": evals_per_step, "bins": BINS,
+            "config": {"workload": (workload_name.replace(" per GPU", " in all, its cells dealt to the ranks") if strong else workload_name) +
+                                   ", 256-bin NMI (SUC), render axis sharded by rank",
+                       "width": WIDTH, "height": HEIGHT, "renders_per_gpu": s_local, "warps_per_gpu": w_local, "warps": WN_total,
+                       "candidates_per_gpu": per_launch_evals, "candidates_total": evals_per_step, "bins": BINS,
                        "collective": "none" if dist is None else
-                       ("8-byte MAX all-reduce (RCCL) per step" if args.blocking or bucket == 1 else
-                        f"MAX all-reduce (RCCL) of the 8-byte winners, {bucket} steps per message")},
+                       ("8-byte MAX all-reduce per step" if blocking_mode or bucket == 1 else
+                        f"MAX all-reduce of the 8-byte winners, {bucket} steps per message")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_pmc_traffic() if args.config == "c2" else None,
                          "lds": load_pmc_lds() if args.config == "c2" else None,
                          "static": static_profile_stamp() if args.config == "c2" else None,
                          "note": "frac is the contract's ALGORITHMIC fraction (2*W*H+4 bytes per evaluation / kernel time / 8 TB/s); "
                                  "the inputs live in L2 / Infinity Cache (traffic) and the kernel is bound by LDS atomic issue, see lds",
-                         "kernel": "nmi_grid_kernel", "kernel_ms": kernel_ms, "kernel_ms_exclusive": kernel_ms_exclusive,
+                         "kernel": f"nmi_pix_kernel ({pix} pixel ranges per candidate)" if pix else "nmi_grid_kernel", "kernel_ms": kernel_ms, "kernel_ms_exclusive": kernel_ms_exclusive,
                          "algorithmic_bytes_per_launch": per_launch_evals * algorithmic_bytes_per_eval(WIDTH, HEIGHT)},
         }
         if world == 1 and not args.no_cpu_baseline:
