@@ -24,6 +24,7 @@
 #include "cudaf_shim.hpp"
 #include "nmi_hip.h"
 #include "nmi_host.h"
+#include "nmi_rating.hpp"
 #include "nmi_search_kernel.hpp"
 
 #define CHECK_HIP(x)                                                                       \
@@ -259,6 +260,45 @@ int main()
                reps * n_r * n_w, w, h, dt / (reps * n_r * n_w) * 1e6, rate);
         printf("SHIM_EVALS_PER_S %.0f\n", rate);
         ok = ok && same && distinct;
+        // The two lines BEHIND the call in the reference's loop, unchanged as well (src/Tracking.cc:1895, :1905): the score goes
+        // into the six-level rating table, helperFunctions::find_max_elements picks the winner (host/nmi_rating.hpp: the table is
+        // a view over the flat array nmi_search_grid writes).  Same winner as one nmi_search_grid call over the same stacks.
+        {
+            NmiSearchKernel kern(n_r, 1, 1, 3, 3, 1, 0.2f, 0.2f, 0.5f, 0.02f, 0.02f, 0.05f);
+            NmiRatingTable rating(kern);
+            for (int sX = 0; sX < kern.getNumSynthX(); sX++)
+                for (int wX = 0; wX < kern.getNumWarpX(); wX++)
+                    for (int wY = 0; wY < kern.getNumWarpY(); wY++) {
+                        const int sY = 0, sZ = 0, wZ = 0, v = wY * kern.getNumWarpX() + wX;
+                        float nmi = -1.0f;
+                        CUDAF::NMIWithCuda_noMask((cv::cuda::PtrStep<unsigned char> *)(d_img + (size_t)(n_r + v) * w * h), SUC, MATCHING_NMI, w, h,
+                                                  &nmi, 100u + sX);
+                        rating[wZ][wY][wX][sZ][sY][sX] = nmi;
+                    }
+            std::vector<NmiSearchKernel> maxElements = helperFunctions::find_max_elements(rating, kern);
+            nmi_params p640;
+            CHECK_NMI(nmi_params_default(&p640, w, h));
+            nmi_ctx *c640 = nullptr;
+            CHECK_NMI(nmi_create(&p640, &c640));
+            int64_t gi = -1;
+            float gs = 0;
+            float *d_tab = nullptr;
+            CHECK_HIP(hipMalloc((void **)&d_tab, (size_t)n_r * n_w * sizeof(float)));
+            CHECK_NMI(nmi_search_grid(c640, d_img, n_r, d_img + (size_t)n_r * w * h, n_w, d_tab, &gi, &gs));
+            std::vector<float> grid_tab((size_t)n_r * n_w);
+            CHECK_HIP(hipMemcpy(grid_tab.data(), d_tab, grid_tab.size() * sizeof(float), hipMemcpyDeviceToHost));
+            bool same_table = true;
+            for (size_t k = 0; k < grid_tab.size(); ++k) same_table = same_table && grid_tab[k] == rating.flat()[k];
+            const bool same_winner = maxElements.size() >= 1 && maxElements[0].getNmi() == gs &&
+                                     (int64_t)(maxElements[0].getBestWarpY() * 3 + maxElements[0].getBestWarpX()) * n_r + maxElements[0].getBestSynthX() == gi;
+            printf("rating[wZ][wY][wX][sZ][sY][sX] + helperFunctions::find_max_elements: %zu winner(s), first = synth %d warp (%d, %d) NMI %.7f; "
+                   "nmi_search_grid: index %lld NMI %.7f; tables %s\n", maxElements.size(), maxElements.empty() ? -1 : maxElements[0].getBestSynthX(),
+                   maxElements.empty() ? -1 : maxElements[0].getBestWarpX(), maxElements.empty() ? -1 : maxElements[0].getBestWarpY(),
+                   maxElements.empty() ? 0.0f : maxElements[0].getNmi(), (long long)gi, gs, same_table ? "equal" : "DIFFER");
+            ok = ok && same_winner && same_table;
+            (void)hipFree(d_tab);
+            nmi_destroy(c640);
+        }
         // the same loop with the two extra lines a host may add: BeginBatch() before the warp loop, Flush() after it
         std::vector<float> batched(n_r * n_w, -1.0f);
         auto pass_batched = [&](std::vector<float> &outv) {

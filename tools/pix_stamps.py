@@ -2,6 +2,8 @@
 """Where the workgroups of nmi_pix_kernel (mid-size grids: P pixel ranges per candidate) spend their time: wall_clock64
 stamps (100 MHz) of every workgroup of one launch (NMI_OPT_STAMPS).  python tools/pix_stamps.py [S Wn [P]]"""
 import os, sys
+EVENTS = "--events" in sys.argv  # record HIP events around the stamped launch (does the marker ahead of it change the start skew?)
+sys.argv = [x for x in sys.argv if x != "--events"]
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -37,6 +39,7 @@ with nmi.NmiContext(w, h) as ctx:
     ctx.set_profiling(False)
     print(f"{S}x{Wn}, {P} ranges: nmi_pix_kernel {np.median(d) * 1e3:.1f} us (HIP events, unstamped)")
     ctx.set_option(ctx.OPT_STAMPS, st.data_ptr())
+    ctx.set_profiling(EVENTS)
     for rep in range(3):
         st.zero_()
         torch.cuda.synchronize()

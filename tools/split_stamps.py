@@ -2,6 +2,8 @@
 """Where a part of the split kernel spends its time: wall_clock64 stamps (100 MHz) at the phase boundaries of every
 workgroup of one launch (NMI_OPT_STAMPS).  python tools/split_stamps.py [S Wn [K]]"""
 import os, sys
+EVENTS = "--events" in sys.argv  # record HIP events around the stamped launch (does the marker ahead of it change the start skew?)
+sys.argv = [x for x in sys.argv if x != "--events"]
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -28,6 +30,7 @@ with nmi.NmiContext(w, h) as ctx:
     for rep in range(5):
         ctx.search_grid(rs, ws)
     ctx.set_option(ctx.OPT_STAMPS, st.data_ptr())
+    ctx.set_profiling(EVENTS)
     for rep in range(2):
         st.zero_()
         torch.cuda.synchronize()
@@ -39,6 +42,7 @@ with nmi.NmiContext(w, h) as ctx:
         print(f"launch {rep}: {live.sum()} working workgroups of {n_wg}")
         dur = (a[live, 6] - a[live, 0]) / 100.0
         print(f"  shader clock over the workgroups' lifetimes: {np.mean(a[live, 7] / dur) / 1e3:.2f} GHz (clock64 ticks / wall us)")
+        print(f'    start: mean {np.mean(a[live, 0] - t0) / 100:.2f} us  max {np.max(a[live, 0] - t0) / 100:.2f}; by XCD (block % 8): ' + '  '.join(f'{np.mean(a[live, 0][np.nonzero(live)[0] % 8 == x] - t0) / 100:.2f}' for x in range(8)))
         for k in range(1, 7):
             col = a[live, k]
             col = col[col > 0]
