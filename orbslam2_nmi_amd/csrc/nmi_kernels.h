@@ -51,9 +51,9 @@ struct GridArgs {
     int s_offset, S_total;        // position of this shard in the global grid
     int w_offset;                 // first warp of this shard in the global grid (0 unless the warp axis is sharded)
     int width, height, npix;
-    int chunks_per_row;           // width / 16 when vec_ok
+    int chunks_per_row;           // width / 16 (1 for frames narrower than 32 pixels)
     uint32_t cpr_magic;           // ceil(2^32 / chunks_per_row)
-    int vec_ok;                   // width % 16 == 0, width >= 32 and both stacks 16-byte aligned
+    int vec_ok;                   // width % 16 == 0, width >= 32 and both stacks 16-byte aligned: rows are whole aligned chunks
     // 16-byte chunk c of the frame (row y = c / chunks_per_row) meets render chunk c + flip_base + y * flip_row:
     // (0, 0) for a top-down render, ((H - 1) * cpr, -2 * cpr) for a bottom-up one (NMI.cu:82)
     int flip_base, flip_row;
@@ -94,7 +94,9 @@ inline void set_geometry(GridArgs &a, int width, int height, const void *render_
     a.height = height;
     a.npix = width * height;
     a.vec_ok = (width % 16 == 0) && width >= 32 && (((uintptr_t)render_stack | (uintptr_t)warp_stack) % 16 == 0);
-    a.chunks_per_row = a.vec_ok ? width / 16 : 1;
+    // widths that are not multiples of 16 (KITTI's 1241) and unaligned stacks: nmi_grid_kernel_rows takes floor(width / 16)
+    // 16-byte chunks of every row with unaligned loads and the rows' last width % 16 pixels one by one (launch_grid)
+    a.chunks_per_row = width >= 32 ? width / 16 : 1;
     a.cpr_magic = a.chunks_per_row > 1 ? (uint32_t)((0x100000000ull + a.chunks_per_row - 1) / a.chunks_per_row) : 0u;
     a.flip = render_bottom_up ? 1 : 0;
     a.flip_base = render_bottom_up ? (height - 1) * a.chunks_per_row : 0;
@@ -106,6 +108,9 @@ hipError_t launch_grid(const GridArgs &a, int workgroups, bool use_bg, hipStream
 // The same kernel as the fallback behind launch_fewlevels: it returns at once unless a.plan->use == 0.  Fewer than 256 bins
 // only with the background rule on.
 hipError_t launch_grid_gated(const GridArgs &a, int workgroups, bool use_bg, hipStream_t stream);
+// nmi_grid_kernel for frames whose rows are not whole aligned 16-byte chunks (width % 16 != 0, or stacks that are not 16-byte
+// aligned; width >= 32): nmi_kernels_rows.hip.  launch_grid sends such launches there itself.
+hipError_t launch_grid_rows(const GridArgs &a, int workgroups, bool use_bg, hipStream_t stream);
 // tools only (NMI_OPT_STAMPS): nmi_grid_kernel with wall-clock stamps at its phase boundaries (nmi_kernels_stamped.hip)
 hipError_t launch_grid_stamped(const GridArgs &a, int workgroups, hipStream_t stream);
 

@@ -263,20 +263,33 @@ __device__ __forceinline__ void add_chunk(Lds &lds, int par, const uint4 &rv, co
 // Histogram phase for one candidate: histogram256Kernel's pixel loop, NMI.cu:79-87.
 // NT lanes (tid = 0..NT-1) share the pixels of the candidate -- on the 16-byte path the 16-pixel chunks [c_first, c_end)
 // of it (the whole pair: 0, npix / 16; nmi_pix_kernel.hip gives each of a candidate's workgroups a range of its own).
-template <bool BG, bool SHIFTED, int HIST, int NT, bool FOLD = true>
+// ROWS (nmi_kernels_rows.hip only): rows that are not whole aligned chunks -- width % 16 != 0 (KITTI's 1241 x 376), or stacks
+// that are not 16-byte aligned.  Chunk c = (row y, j-th chunk of the row) starts at byte y * width + 16 j of the frame and at
+// ry * width + 16 j of the render (unaligned 16-byte loads); the width % 16 pixels left at the end of every row are added one
+// by one after the loop.  c_end is then height * (width / 16).  (Through the byte path below such frames took 4.1x the time per
+// pixel: profiles/r04_a/odd_width_time.txt.)
+template <bool BG, bool SHIFTED, int HIST, int NT, bool FOLD = true, bool ROWS = false>
 __device__ __forceinline__ void histogram_phase(Lds &lds, int par, const GridArgs &a, const uint8_t *__restrict__ render,
                                                 const uint8_t *__restrict__ warped, int tid, int c_first, int c_end)
 {
-    if (a.vec_ok) {
+    if (ROWS || a.vec_ok) {
         // 16 pixels per lane per step: one 16-byte load from each image (1 KiB per wavefront instruction),
         // the next step's loads issued before this step's atomics.
         const int nchunks = c_end;
         // 32-bit unsigned byte offsets from the (scalar) image bases: one shift per load instead of 64-bit pointer math
-        auto ldw = [&](int c) { return *reinterpret_cast<const uint4 *>(warped + ((uint32_t)c << 4)); };
+        const int row_rem = ROWS ? a.width - (a.chunks_per_row << 4) : 0;  // pixels of a row beyond its whole chunks
+        auto ldw = [&](int c) {
+            if (ROWS) return *reinterpret_cast<const uint4 *>(warped + (((uint32_t)c << 4) + (uint32_t)__mul24((int)__umulhi((uint32_t)c, a.cpr_magic), row_rem)));
+            return *reinterpret_cast<const uint4 *>(warped + ((uint32_t)c << 4));
+        };
         // NMI.cu:82: row y of the frame meets row H-1-y of a bottom-up render.  Branch-free for both orientations:
         // render chunk = c + flip_base + y * flip_row with y = c / chunks_per_row (multiply-high by the magic).
         auto ldr = [&](int c) {
             const int y = (int)__umulhi((uint32_t)c, a.cpr_magic);
+            if (ROWS) {
+                const int ry = a.flip ? a.height - 1 - y : y;
+                return *reinterpret_cast<const uint4 *>(render + (((uint32_t)(__mul24(y, a.flip_row) + c + a.flip_base) << 4) + (uint32_t)__mul24(ry, row_rem)));
+            }
             return *reinterpret_cast<const uint4 *>(render + ((uint32_t)(__mul24(y, a.flip_row) + c + a.flip_base) << 4));
         };
         // Fast loop.  Software pipeline with two named register sets: the loads of the chunk after next are in flight
@@ -326,6 +339,26 @@ __device__ __forceinline__ void histogram_phase(Lds &lds, int par, const GridArg
                 add_chunk<BG, SHIFTED, HIST, true>(lds, par, rc, wc, a.shift, try_flat);
                 wc = wn;
                 rc = rn;
+            }
+        }
+        if (ROWS && row_rem > 0) {
+            // the last width % 16 pixels of every row
+            const int x0 = a.chunks_per_row << 4, n = a.height * row_rem;
+            for (int t = tid; t < n; t += NT) {
+                const int y = t / row_rem, x = x0 + t - y * row_rem;
+                const int ry = a.flip ? (a.height - 1 - y) : y;
+                uint32_t d1 = render[ry * a.width + x], d2 = warped[y * a.width + x];
+                if (HIST == 2) {
+                    if (BG || (d1 != 0 && d2 != 0)) {
+                        if (SHIFTED) {
+                            d1 >>= a.shift;
+                            d2 >>= a.shift;
+                        }
+                        (void)__hip_atomic_fetch_add(&lds.joint[joint_word(d1, d2)], joint_inc(d2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                } else {
+                    add_pixel<BG, SHIFTED>(lds, par, d1, d2, a.shift);
+                }
             }
         }
     } else {
@@ -592,13 +625,14 @@ __device__ __forceinline__ void finish_search(const GridArgs &a, int lane, unsig
 // AFTER their hot loop, never inside it: inlined into the hot loop it cost ~10 % there (spills, code size), and as a
 // real function call inside the loop ~25 %.  Uses the parity-0 event list / total and leaves them, hist_warped and
 // the joint counters zero.
-template <bool SHIFTED, bool BG = true>
+template <bool SHIFTED, bool BG = true, bool ROWS = false>
 __device__ __forceinline__ void exact_candidate(Lds &lds, const GridArgs &a, int tid, int p, unsigned long long &prev_key)
 {
     const int lane = tid & 63, wave = tid >> 6;
     const int w = p / a.S_local, s = p - w * a.S_local;
     __syncthreads();  // wavefront 0 may still be finishing the previous candidate's final phase (it resets shared state)
-    histogram_phase<true, SHIFTED, 1, kBlock>(lds, 0, a, a.render_stack + (size_t)s * a.npix, a.warp_stack + (size_t)w * a.npix, tid, 0, a.npix >> 4);
+    histogram_phase<true, SHIFTED, 1, kBlock, true, ROWS>(lds, 0, a, a.render_stack + (size_t)s * a.npix, a.warp_stack + (size_t)w * a.npix, tid, 0,
+                                                          ROWS ? a.height * a.chunks_per_row : a.npix >> 4);
     __syncthreads();
     decode_phase<!BG>(lds, 0, a, wave, lane);
     __syncthreads();
@@ -638,6 +672,8 @@ __device__ __forceinline__ void exact_candidate(Lds &lds, const GridArgs &a, int
 #define NMI_GRID_KERNEL_NAME nmi_grid_kernel_gated
 #elif defined(NMI_GRID_KERNEL_STAMPED)
 #define NMI_GRID_KERNEL_NAME nmi_grid_kernel_stamped
+#elif defined(NMI_GRID_KERNEL_ROWS)
+#define NMI_GRID_KERNEL_NAME nmi_grid_kernel_rows
 #else
 #define NMI_GRID_KERNEL_NAME nmi_grid_kernel
 #endif
@@ -667,6 +703,13 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void NMI_GRID_KERNEL_NAME(GridAr
     NMI_GRID_STAMP(0);
     constexpr bool kOptimistic = HIST == 3;
     constexpr int kFirst = kOptimistic ? 2 : HIST;
+#ifdef NMI_GRID_KERNEL_ROWS
+    constexpr bool kRows = true;  // rows that are not whole aligned chunks (histogram_phase)
+#define NMI_ALL_CHUNKS (a.height * a.chunks_per_row)
+#else
+    constexpr bool kRows = false;
+#define NMI_ALL_CHUNKS (a.npix >> 4)
+#endif
     // Background rule off (NMI.cu:85) on the optimistic path: every pixel is counted, so that the wrap detector knows the
     // expected total (W*H), and decode_phase clears the row and the column of intensity 0 -- the skipped pixels.  Only
     // with 256 bins: the rule looks at the intensity before the shift, and bin 0 of a shifted histogram also holds
@@ -710,9 +753,9 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void NMI_GRID_KERNEL_NAME(GridAr
 
         if (a.phase_mask & 1) {
             if (a.phase_mask & 8) {  // ablation: only half of the wavefronts take part in the histogram phase
-                if (wave < kWaves / 2) histogram_phase<kCountAll, SHIFTED, kFirst, kBlock / 2>(lds, par, a, render, warped, tid, 0, a.npix >> 4);
+                if (wave < kWaves / 2) histogram_phase<kCountAll, SHIFTED, kFirst, kBlock / 2, true, kRows>(lds, par, a, render, warped, tid, 0, NMI_ALL_CHUNKS);
             } else
-                histogram_phase<kCountAll, SHIFTED, kFirst, kBlock>(lds, par, a, render, warped, tid, 0, a.npix >> 4);
+                histogram_phase<kCountAll, SHIFTED, kFirst, kBlock, true, kRows>(lds, par, a, render, warped, tid, 0, NMI_ALL_CHUNKS);
         }
         if (table_pending) {
 #pragma unroll
@@ -756,7 +799,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void NMI_GRID_KERNEL_NAME(GridAr
         if (tid < 2) lds.total[tid] = lds.ovf_n[tid] = 0;
         if (tid < 2 * kSide) (&lds.side_key[0][0])[tid] = (&lds.side_cnt[0][0])[tid] = 0;
         __syncthreads();
-        for (int o = exact_from; o < total; o += gridDim.x) exact_candidate<SHIFTED, !kZero0>(lds, a, tid, candidate_at(a, o), prev_key);
+        for (int o = exact_from; o < total; o += gridDim.x) exact_candidate<SHIFTED, !kZero0, kRows>(lds, a, tid, candidate_at(a, o), prev_key);
     }
 
     if (wave == 0 && !(a.phase_mask & 16)) {  // bit 4: timing experiment without the protocol (no result)
@@ -768,7 +811,30 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void NMI_GRID_KERNEL_NAME(GridAr
     NMI_GRID_STAMP(6);
 }
 
-#if defined(NMI_GRID_KERNEL_STAMPED)
+#if defined(NMI_GRID_KERNEL_ROWS)
+hipError_t launch_grid_rows(const GridArgs &a, int workgroups, bool use_bg, hipStream_t stream)
+{
+    if (a.width < 32 || (a.hist_variant != 1 && a.hist_variant != 3)) return hipErrorInvalidValue;
+    const dim3 grid(workgroups), block(kBlock);
+    const bool exact_only = a.hist_variant == 1 || (!use_bg && a.shift != 0);  // (as launch_grid: BG off below 256 bins has no optimistic path)
+    if (exact_only) {
+        if (use_bg) {
+            if (a.shift != 0) hipLaunchKernelGGL((nmi_grid_kernel_rows<true, true, 1>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((nmi_grid_kernel_rows<true, false, 1>), grid, block, 0, stream, a);
+        } else {
+            if (a.shift != 0) hipLaunchKernelGGL((nmi_grid_kernel_rows<false, true, 1>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((nmi_grid_kernel_rows<false, false, 1>), grid, block, 0, stream, a);
+        }
+    } else if (a.shift != 0) {
+        hipLaunchKernelGGL((nmi_grid_kernel_rows<true, true, 3>), grid, block, 0, stream, a);
+    } else if (use_bg) {
+        hipLaunchKernelGGL((nmi_grid_kernel_rows<true, false, 3>), grid, block, 0, stream, a);
+    } else {
+        hipLaunchKernelGGL((nmi_grid_kernel_rows<false, false, 3>), grid, block, 0, stream, a);
+    }
+    return hipGetLastError();
+}
+#elif defined(NMI_GRID_KERNEL_STAMPED)
 // tools only: 256 bins, background rule on, default histogram variant
 hipError_t launch_grid_stamped(const GridArgs &a, int workgroups, hipStream_t stream)
 {
@@ -1051,6 +1117,9 @@ static void launch_hist(const GridArgs &a, dim3 grid, dim3 block, bool use_bg, h
 hipError_t launch_grid(const GridArgs &a, int workgroups, bool use_bg, hipStream_t stream)
 {
     dim3 grid(workgroups), block(kBlock);
+    // rows that are not whole aligned 16-byte chunks: the unaligned-row form instead of the byte path (frames under 32 pixels
+    // of width keep the byte path)
+    if (!a.vec_ok && a.width >= 32 && (a.hist_variant == 1 || a.hist_variant == 3) && !(a.phase_mask & 8)) return launch_grid_rows(a, workgroups, use_bg, stream);
     switch (a.hist_variant) {
     case 1: launch_hist<1>(a, grid, block, use_bg, stream); break;
     case 3:

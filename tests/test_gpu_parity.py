@@ -171,6 +171,63 @@ def test_ragged_widths_take_the_generic_path(nmi, shape, split_mode):
             check_pair(nmi, oc, r, f, bg=bg, bu=bu)
 
 
+@pytest.mark.parametrize("shape", [(641, 48), (1241, 24), (100, 60), (333, 21), (47, 33), (640, 30)])
+def test_grids_whose_rows_are_not_whole_chunks(nmi, shape):
+    """Widths that are not multiples of 16 (KITTI: 1241) and stacks that are not 16-byte aligned: nmi_grid_kernel_rows (floor(W / 16)
+    unaligned 16-byte chunks per row + the rows' last pixels one by one) -- every switch, and a pair that wraps the 16-bit counters
+    (exact path), against the oracle with ==."""
+    from oracle import binding as oc
+    w, h = shape
+    rng = np.random.default_rng(w * 7 + h)
+    S, Wn = 5, 4
+    base = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    rs = np.stack([np.clip(np.roll(base, s - 2, axis=1).astype(int) + rng.integers(-6, 7, (h, w)), 0, 255).astype(np.uint8) for s in range(S)])
+    ws = np.stack([np.clip(np.roll(base, v - 1, axis=0).astype(int) + rng.integers(-9, 10, (h, w)), 0, 255).astype(np.uint8) for v in range(Wn)])
+    rs[:, :3, :] = 255          # a flat band: folded chunks on this path too
+    ws[:, :3, :] = 0
+    rs[4] = 200                 # constant pair: one bin takes every pixel (wraps 16 bits when W * H > 65535 -- not at these sizes -- and
+    ws[3] = 17                  # takes the flat-region side counters in any case)
+    # misaligned copies: the same bytes one byte further on
+    buf_r = torch.zeros(rs.size + 16, dtype=torch.uint8, device="cuda")
+    buf_w = torch.zeros(ws.size + 16, dtype=torch.uint8, device="cuda")
+    for off in ((0, 0), (1, 3)) if w % 16 == 0 else ((0, 0),):
+        dr = buf_r[off[0]:off[0] + rs.size].view(S, h, w)
+        dw = buf_w[off[1]:off[1] + ws.size].view(Wn, h, w)
+        dr.copy_(torch.from_numpy(rs).cuda())
+        dw.copy_(torch.from_numpy(ws).cuda())
+        for bg, bins, mode, bu in [(True, 256, 1, True), (False, 256, 1, False), (True, 64, 0, True), (False, 32, 1, True), (True, 256, 0, False)]:
+            with oc.rounded():
+                ro, io, bo = oc.search_grid(rs, ws, render_bottom_up=bu, threads=8, use_bg=bg, mode=mode, shift={256: 0, 64: 2, 32: 3}[bins])
+            with nmi.NmiContext(w, h, render_bottom_up=bu, use_bg=bg, mode=mode, bins=bins) as ctx:
+                ctx.set_option(ctx.OPT_SPLIT, 0)      # the one-workgroup-per-candidate kernel, whatever the grid's size
+                t = torch.zeros((Wn, S), device="cuda")
+                got = ctx.search_grid(dr, dw, t)
+            assert got == (io, bo), (shape, off, bg, bins, mode, bu)
+            assert (t.cpu().numpy().view(np.uint32) == ro.view(np.uint32)).all(), (shape, off, bg, bins, mode, bu)
+
+
+def test_rows_form_at_kitti_size_with_counter_wraps(nmi):
+    """1241 x 376: a textured pair and a two-level pair whose bins exceed 65,535 hits (optimistic pass fails its pixel-count test,
+    the exact pass with returning atomics follows) -- both through the unaligned-row form."""
+    from oracle import binding as oc
+    w, h = 1241, 376
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    b = np.clip(a.astype(int) + rng.integers(-12, 13, (h, w)), 0, 255).astype(np.uint8)
+    two = np.where((xx + yy) % 2 == 0, 10, 200).astype(np.uint8)
+    tw2 = np.where((xx // 2 + yy) % 2 == 0, 30, 90).astype(np.uint8)
+    rs, ws = np.stack([a, two]), np.stack([b, tw2])
+    with oc.rounded():
+        ro, io, bo = oc.search_grid(rs, ws, render_bottom_up=True, threads=4)
+    with nmi.NmiContext(w, h) as ctx:
+        ctx.set_option(ctx.OPT_SPLIT, 0)
+        t = torch.zeros((2, 2), device="cuda")
+        got = ctx.search_grid(dev(rs), dev(ws), t)
+    assert got == (io, bo)
+    assert (t.cpu().numpy().view(np.uint32) == ro.view(np.uint32)).all()
+
+
 @pytest.mark.parametrize("bins", [256, 128, 64, 32, 16])
 def test_bins(nmi, bins, split_mode):
     from oracle import binding as oc
