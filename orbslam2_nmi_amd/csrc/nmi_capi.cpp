@@ -117,14 +117,18 @@ static void choose_split(const nmi_ctx *ctx, int64_t total, int cap, int *parts,
 int choose_pix(const nmi_ctx *ctx, const nmi::GridArgs &a, int64_t total, int cap)
 {
     if (cap > ctx->compute_units) cap = ctx->compute_units;  // (an owner that waits for a CU starts a second round)
-    if (ctx->hist_variant != 3 || !a.vec_ok || (ctx->shift != 0 && !ctx->params.use_bg) || ctx->pair_renders || total <= 0) return 0;
+    if (ctx->hist_variant != 3 || a.width < 32 || (ctx->shift != 0 && !ctx->params.use_bg) || ctx->pair_renders || total <= 0) return 0;
     if ((ctx->phase_mask & ~512) != 3 || (a.dbg_stamps != nullptr && ctx->split_mode != 1)) return 0;
     if (ctx->split_mode == 1) {
         const int p = ctx->split_pixels;
         return (p >= 2 && p <= nmi::pix_max_ranges() && total * p <= cap) ? p : 0;
     }
-    if (ctx->split_mode != -1 || ctx->split_pixels != -1 || total <= 32 || total * 2 > cap) return 0;
+    if (ctx->split_mode != -1 || ctx->split_pixels != -1 || total * 2 > cap) return 0;
     const int p = (int)(cap / total);
+    // Frames whose rows are not whole aligned 16-byte chunks (width % 16 != 0, unaligned stacks): the row-split kernel would
+    // read them byte by byte, this one has the unaligned-row form -- so small grids and single pairs come here too, with more ranges
+    if (!a.vec_ok) return p > nmi::pix_max_ranges() ? nmi::pix_max_ranges() : p;
+    if (total <= 32) return 0;
     return p > 3 ? 3 : p;
 }
 

@@ -101,12 +101,19 @@ template <bool SHIFTED>
 __device__ __forceinline__ void histogram_dealt(Lds &lds, const GridArgs &a, const uint8_t *__restrict__ render, const uint8_t *__restrict__ warped,
                                                 int wave, int lane, const Deal &d)
 {
-    const int nchunks = a.npix >> 4, last = nchunks - 1;
-    auto ldw = [&](int c) { return *reinterpret_cast<const uint4 *>(warped + ((uint32_t)min(c, last) << 4)); };
-    auto ldr = [&](int c) {  // NMI.cu:82: row y of the frame meets row H-1-y of a bottom-up render (histogram_phase)
+    // chunk c = the j-th 16-byte chunk of row y: byte y * width + 16 j of the frame, ry * width + 16 j of the render -- rows need not
+    // be whole aligned chunks (histogram_phase's ROWS form, nmi_kernels.hip; row_rem = width % 16 pixels per row are left for
+    // add_row_tails below)
+    const int nchunks = a.height * a.chunks_per_row, last = nchunks - 1, row_rem = a.width - (a.chunks_per_row << 4);
+    auto ldw = [&](int c) {
+        c = min(c, last);
+        return *reinterpret_cast<const uint4 *>(warped + (((uint32_t)c << 4) + (uint32_t)__mul24((int)__umulhi((uint32_t)c, a.cpr_magic), row_rem)));
+    };
+    auto ldr = [&](int c) {  // NMI.cu:82: row y of the frame meets row H-1-y of a bottom-up render
         c = min(c, last);
         const int y = (int)__umulhi((uint32_t)c, a.cpr_magic);
-        return *reinterpret_cast<const uint4 *>(render + ((uint32_t)(__mul24(y, a.flip_row) + c + a.flip_base) << 4));
+        const int ry = a.flip ? a.height - 1 - y : y;
+        return *reinterpret_cast<const uint4 *>(render + (((uint32_t)(__mul24(y, a.flip_row) + c + a.flip_base) << 4) + (uint32_t)__mul24(ry, row_rem)));
     };
     // chunk of this lane in the workgroup's iteration `it`; beyond the workgroup's pieces: some chunk >= nchunks (not added)
     auto chunk_of = [&](int it) {
@@ -116,6 +123,19 @@ __device__ __forceinline__ void histogram_dealt(Lds &lds, const GridArgs &a, con
         return i < d.n ? (t << 6) + lane : 0x7FFFFFC0;
     };
     const int iters = (d.n + kWaves - 1) / kWaves;  // workgroup-uniform
+    if (d.off == 0 && row_rem > 0) {
+        // the owner also adds the last width % 16 pixels of every row
+        const int x0 = a.chunks_per_row << 4, n = a.height * row_rem;
+        for (int t = wave * 64 + lane; t < n; t += kBlock) {
+            const int y = t / row_rem, x = x0 + t - y * row_rem;
+            uint32_t d1 = render[(a.flip ? a.height - 1 - y : y) * a.width + x], d2 = warped[y * a.width + x];
+            if (SHIFTED) {
+                d1 >>= a.shift;
+                d2 >>= a.shift;
+            }
+            (void)__hip_atomic_fetch_add(&lds.joint[joint_word(d1, d2)], joint_inc(d2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
     if (iters <= 0) return;
     const bool try_flat = !(a.phase_mask & 4);
     int resume = -1;
@@ -308,7 +328,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_pix_kernel(GridArgs a, 
     if (tid < 2) lds.ovf_n[tid] = lds.total[tid] = 0;
     if (tid < 2 * kSide) (&lds.side_key[0][0])[tid] = (&lds.side_cnt[0][0])[tid] = 0;
     if (tid == 0) lds.fallback = 0;
-    // This workgroup's pixels (the host sends only 16-byte-path geometries here).  The owner's share is the larger one: its
+    // This workgroup's pixels (frames of at least 32 pixels of width).  The owner's share is the larger one: its
     // helpers' counters need a few microseconds to reach it, which it spends adding pixels.
     const Deal deal = make_deal(dealing, P, q);
     __syncthreads();
@@ -450,7 +470,7 @@ hipError_t launch_pix(const GridArgs &a, int pix_parts, double owner_share, bool
 {
     const long long total = (long long)a.S_local * a.Wn;
     if (pix_parts < 2 || pix_parts > kMaxRanges || total <= 0 || total * pix_parts > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    if (!a.vec_ok || !a.blocks || a.hist_variant != 3 || (a.shift != 0 && !use_bg) || a.order) return hipErrorInvalidValue;
+    if (a.width < 32 || !a.blocks || a.hist_variant != 3 || (a.shift != 0 && !use_bg) || a.order) return hipErrorInvalidValue;
     // the dealing pattern: own : hlp pieces per period, the closest to the wanted share among periods of at most 48 pieces
     int own = 1, hlp = 1;
     {
@@ -467,7 +487,7 @@ hipError_t launch_pix(const GridArgs &a, int pix_parts, double owner_share, bool
         }
     }
     auto magic = [](int d) { return d > 1 ? (uint32_t)((0x100000000ull + (uint32_t)d - 1) / (uint32_t)d) : 0u; };
-    const int pieces = ((a.npix >> 4) + 63) >> 6, L = own + (pix_parts - 1) * hlp;
+    const int pieces = (a.height * a.chunks_per_row + 63) >> 6, L = own + (pix_parts - 1) * hlp;
     const DealArgs g{own, hlp, magic(own), magic(hlp), pieces / L, pieces % L, magic((int)total)};
     const dim3 grid((unsigned)(total * pix_parts)), block(kBlock);
     if (a.shift != 0)

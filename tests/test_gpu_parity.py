@@ -171,11 +171,12 @@ def test_ragged_widths_take_the_generic_path(nmi, shape, split_mode):
             check_pair(nmi, oc, r, f, bg=bg, bu=bu)
 
 
+@pytest.mark.parametrize("kernel", [0, -1], ids=["grid-kernel", "auto"])
 @pytest.mark.parametrize("shape", [(641, 48), (1241, 24), (100, 60), (333, 21), (47, 33), (640, 30)])
-def test_grids_whose_rows_are_not_whole_chunks(nmi, shape):
+def test_grids_whose_rows_are_not_whole_chunks(nmi, shape, kernel):
     """Widths that are not multiples of 16 (KITTI: 1241) and stacks that are not 16-byte aligned: nmi_grid_kernel_rows (floor(W / 16)
-    unaligned 16-byte chunks per row + the rows' last pixels one by one) -- every switch, and a pair that wraps the 16-bit counters
-    (exact path), against the oracle with ==."""
+    unaligned 16-byte chunks per row + the rows' last pixels one by one), and in automatic mode nmi_pix_kernel, which has the same
+    form (such frames never take the row-split kernel: it would read them byte by byte) -- every switch, against the oracle with ==."""
     from oracle import binding as oc
     w, h = shape
     rng = np.random.default_rng(w * 7 + h)
@@ -199,9 +200,13 @@ def test_grids_whose_rows_are_not_whole_chunks(nmi, shape):
             with oc.rounded():
                 ro, io, bo = oc.search_grid(rs, ws, render_bottom_up=bu, threads=8, use_bg=bg, mode=mode, shift={256: 0, 64: 2, 32: 3}[bins])
             with nmi.NmiContext(w, h, render_bottom_up=bu, use_bg=bg, mode=mode, bins=bins) as ctx:
-                ctx.set_option(ctx.OPT_SPLIT, 0)      # the one-workgroup-per-candidate kernel, whatever the grid's size
+                ctx.set_option(ctx.OPT_SPLIT, kernel)  # 0: the one-workgroup-per-candidate kernel, whatever the grid's size
                 t = torch.zeros((Wn, S), device="cuda")
                 got = ctx.search_grid(dr, dw, t)
+                if kernel == -1 and w >= 32 and (bg or bins == 256) and (w % 16 or off != (0, 0)) and ctx.info()["compute_units"] >= 100:
+                    assert ctx.pix_status()["last_launch_ranges"] == 5
+                pair = ctx.eval_pair(dr[1], dw[2])
+                assert pair == ro[2, 1] or (np.isnan(pair) and np.isnan(ro[2, 1]))
             assert got == (io, bo), (shape, off, bg, bins, mode, bu)
             assert (t.cpu().numpy().view(np.uint32) == ro.view(np.uint32)).all(), (shape, off, bg, bins, mode, bu)
 
