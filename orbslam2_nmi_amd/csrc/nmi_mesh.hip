@@ -786,22 +786,24 @@ __device__ __forceinline__ void mesh_tile_body(const float *__restrict__ xyz, co
     const int bin = blockIdx.x;
     const int s = bin / tiles, tile = bin - s * tiles, tyi = tile / g.tiles_x, txi = tile - tyi * g.tiles_x;
     const int X0 = txi * kTile, Y0 = tyi * kTile;
-    if (tid == 0) {
-        const uint32_t c = g.state[2 * (size_t)bin], f = g.state[2 * (size_t)bin + 1];
-        if (c) g.state[2 * (size_t)bin] = 0u;       // both words are left zero for the next render
-        if (f) g.state[2 * (size_t)bin + 1] = 0u;
-        lds.hdr[0] = c < (uint32_t)g.cap ? c : (uint32_t)g.cap;
-        lds.hdr[1] = f;
-    }
+    // Everything the tile needs from memory is asked for at once: the bin's two state words (every lane, one address: no broadcast
+    // through LDS, no barrier before the tile knows what it holds) and -- speculatively, by lane j -- bin entry j.  The two used to be
+    // dependent round trips with a barrier between them; the key clear runs under their latency.
+    const uint32_t c_raw = g.state[2 * (size_t)bin], f_raw = g.state[2 * (size_t)bin + 1];
+    const uint32_t my_id = tid < g.cap ? g.bins[(size_t)bin * g.stride + tid] : 0u;   // (meaningful for tid < n only)
     if (tid >= 64 && tid < 64 + tex.levels) tex_level_fill(tex, tid - 64, &lds.tex[tid - 64]);
-    __syncthreads();
-    const int n = (int)lds.hdr[0];
-    const bool from_memory = lds.hdr[1] != 0u;
+    for (int i = tid; i < kTile * kTile; i += kTileThreads) lds.keys[i] = kEmptyKey;
+    const int n = (int)(c_raw < (uint32_t)g.cap ? c_raw : (uint32_t)g.cap);
+    const bool from_memory = f_raw != 0u;
     // this lane's output pixels: four in a row, in rows oy and oy + 32
     const int ox = X0 + (tid & 15) * 4, oy = Y0 + (tid >> 4);
     const bool col_ok = ox < width;
     const bool dword_ok = ox + 3 < width && ((width & 3) == 0) && (((uintptr_t)out & 3) == 0);
     if ((n == 0 && !from_memory) || (g.dbg & 8)) {  // nothing was drawn into this tile: background (glClearColor(1,1,1), rendering.hpp:533)
+        if (g.dbg & 8) {   // (measurement switch: the state words still have to be left clean)
+            __syncthreads();
+            if (tid == 0) g.state[2 * (size_t)bin] = g.state[2 * (size_t)bin + 1] = 0u;
+        }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int y = oy + 32 * half;
@@ -815,11 +817,10 @@ __device__ __forceinline__ void mesh_tile_body(const float *__restrict__ xyz, co
         return;
     }
     if (n > 0) {
-        for (int i = tid; i < kTile * kTile; i += kTileThreads) lds.keys[i] = kEmptyKey;
         // ---- set-up: lane j turns bin entry j into a record ------------------------------------------------------------
         uint32_t nst = 0;
         if (tid < n && !(g.dbg & 4)) {
-            const uint32_t id = g.bins[(size_t)bin * g.stride + tid];
+            const uint32_t id = my_id;
             uint32_t *r = lds.rec[tid];
             TriView t;
             float su[3], sv[3];
@@ -858,6 +859,10 @@ __device__ __forceinline__ void mesh_tile_body(const float *__restrict__ xyz, co
         }
         if (lane == 63) lds.wave_sum[wave] = incl;
         __syncthreads();
+        if (tid == 0) {   // every wavefront has read the state words: both are left zero for the next render
+            if (c_raw) g.state[2 * (size_t)bin] = 0u;
+            if (f_raw) g.state[2 * (size_t)bin + 1] = 0u;
+        }
         uint32_t before = 0, total = 0;
 #pragma unroll
         for (int w = 0; w < (BINMAX + 63) / 64; ++w) {
@@ -945,6 +950,9 @@ __device__ __forceinline__ void mesh_tile_body(const float *__restrict__ xyz, co
             }
         }
         __syncthreads();
+    } else {
+        __syncthreads();   // (only what came through the memory buffer: the texture levels' table is in LDS, everyone has read the state words)
+        if (tid == 0) g.state[2 * (size_t)bin + 1] = 0u;
     }
     if (!col_ok) return;
     TexLevel base_level;

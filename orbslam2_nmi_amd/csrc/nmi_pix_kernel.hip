@@ -280,6 +280,59 @@ __device__ __forceinline__ void decode_merged(Lds &lds, const GridArgs &a, int w
     if (i == 0) atomicAdd(&lds.total[0], wave_total);
 }
 
+// final_phase (nmi_kernels.hip: the three 256-element trees of AddVectorPairwiseKernel, NMI.cu:295-339, side by side in DPP rows
+// 0..2, then the score) with one difference: the marginal counts' terms come from the LDS copy of the table where the count is
+// below its 4096 entries (most of a 640x480 frame's 256 marginal bins are) and from memory only above -- the owner scores ONE
+// candidate, so the memory round trip of the lookups is on every launch's critical path instead of hidden behind the next
+// candidate's pixels.  Same values (the LDS table is a copy), same order.
+__device__ __forceinline__ void final_phase_owner(Lds &lds, const GridArgs &a, int lane, int p, int w, int s, unsigned long long &prev_key)
+{
+    const int i = lane & 15, r = lane >> 4;
+    float lo[8], hi[8];
+    const uint32_t *h = r == 0 ? lds.hist_render : lds.hist_warped;
+    uint32_t cl[8], ch[8], cmax = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        cl[k] = r < 2 ? h[i + 16 * k] : 0u;
+        ch[k] = r < 2 ? h[i + 16 * k + 128] : 0u;
+        cmax = max(cmax, max(cl[k], ch[k]));
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        lo[k] = lds.table[cl[k] & (kLdsTable - 1)];
+        hi[k] = lds.table[ch[k] & (kLdsTable - 1)];
+    }
+    if (cmax >= (uint32_t)kLdsTable) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (cl[k] >= (uint32_t)kLdsTable) lo[k] = a.table[cl[k]];
+            if (ch[k] >= (uint32_t)kLdsTable) hi[k] = a.table[ch[k]];
+        }
+    }
+    if ((w == 0 || s == 0) && a.plan) {  // the search as its own content probe (final_phase)
+        uint32_t m = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m |= (cl[k] != 0u ? 1u << k : 0u) | (ch[k] != 0u ? 0x100u << k : 0u);
+        if (lane < 32 && m) __hip_atomic_fetch_or(const_cast<uint32_t *>(&a.plan->seen[lane]), m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (r == 2) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            lo[k] = lds.joint_row_sums[i + 16 * k];
+            hi[k] = lds.joint_row_sums[i + 16 * k + 128];
+        }
+    }
+    const float x = row_tree_16(lane_tree_16(lo, hi));
+    const float a1 = __shfl(x, 0, 64), a2 = __shfl(x, 16, 64), a3 = __shfl(x, 32, 64);
+    if (a.dbg_h1 && lane < 64) {
+        for (int t = lane; t < kBins; t += 64) {
+            a.dbg_h1[t] = lds.hist_render[t];
+            if (a.dbg_h2) a.dbg_h2[t] = lds.hist_warped[t];
+        }
+    }
+    if (lane == 0) commit_score(a, p, w, s, a1, a2, a3, prev_key);
+}
+
 }  // namespace
 
 size_t pix_block_bytes(int candidates, int pix_parts) { return (size_t)candidates * (size_t)(pix_parts - 1) * kPixBlockBytes; }
@@ -440,7 +493,7 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void nmi_pix_kernel(GridArgs a, 
         __syncthreads();
         stamp(5);
         alone = lds.total[0] != (uint32_t)a.npix;  // some 16-bit field wrapped (workgroup-uniform, rare)
-        if (!alone && wave == 0) final_phase(lds, a, lane, p, w, s, prev_key);
+        if (!alone && wave == 0) final_phase_owner(lds, a, lane, p, w, s, prev_key);
     } else if (tid == 0 && timeouts) {
         __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
