@@ -346,7 +346,7 @@ int nmi_last_kernel_ms(nmi_ctx *ctx, float *h_ms);
  */
 #define NMI_OPT_HIST_VARIANT 1 /* 3 optimistic + verify + exact redo (default), 1 exact wrap bookkeeping throughout.  The
                                   experiments 0 (per-pixel wrap test), 2 (unchecked) and 4 (histogram and decode overlapped by
-                                  wavefront role; exact but slower) exist only in a library built with
+                                  wavefront role; exact but slower, profiles/NOTES.md) exist only in a library built with
                                   -DNMI_BUILD_ABLATIONS (NMI_ERR_UNSUPPORTED otherwise). */
 #define NMI_OPT_PHASE_MASK 2   /* bit 0 histogram phase, bit 1 decode + score, bit 2 disable the flat-chunk shortcut; default 3.
                                   Bit 9 (tests): one part of the split kernel withholds its hand-off, so the bounded wait (2 ms) of

@@ -43,7 +43,7 @@ def is_stale():
     return any(os.path.getmtime(f) > t for f in sources() + headers() + [os.path.abspath(__file__)])
 
 
-# The experiments of DESIGN.md section 4 (histogram variants 0 / 2 / 4) are not part of the shipped library; a second
+# The experiments of profiles/NOTES.md (histogram variants 0 / 2 / 4) are not part of the shipped library; a second
 # library with them is built on request:  python -m orbslam2_nmi_amd.build --ablations  -> lib/libnmi_hip_ablate.so, which
 # tools/ablate.py loads through NMI_HIP_LIBRARY.
 ABLATE_LIB = os.path.join(LIB_DIR, "libnmi_hip_ablate.so")

@@ -858,12 +858,12 @@ hipError_t launch_grid_gated(const GridArgs &a, int workgroups, bool use_bg, hip
 }
 #else  // everything below belongs to the primary translation unit only
 
-#ifdef NMI_BUILD_ABLATIONS  // experiments kept for tools/ablate.py; not part of the shipped library
+#ifdef NMI_BUILD_ABLATIONS  // experiments kept for tools/ablate.py; not part of the shipped library (profiles/NOTES.md)
 // ---------------------------------------------------------------------------------------------------------
 // Pipelined ("wavefront-specialised") form of the same computation (NMI_OPT_HIST_VARIANT = 4, experimental).
 // Exact, covered by the parity tests, but measured SLOWER than the sequential kernel on MI355X (114 vs 95 us per 729
 // candidates): the decode wavefronts take issue slots from the histogram wavefronts, 8 histogram wavefronts add
-// pixels 22 % slower than 16, and the drain is a third serial step.  Kept as an ablation; see DESIGN.md section 4.
+// pixels 22 % slower than 16, and the drain is a third serial step.  Kept as an ablation; see profiles/NOTES.md.
 //
 // The histogram phase is bound by the LDS atomic unit, the decode arithmetic by VALU issue and latency; run one
 // after the other (kernel above) a CU leaves each unit idle in turn.  Here the 16 wavefronts split into

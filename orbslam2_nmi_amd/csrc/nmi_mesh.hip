@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void nmi_mesh_bin_kernel(const float *__restri
 {
     // The triangle blocks come first in the launch: what they take is round trips (frustum test, appends) on the few hundred of
     // them that see anything, and those should start at once; the warp blocks are plain arithmetic and fill in behind
-    // (warp blocks first: 30.4 / 55.8 us for this kernel in a level of 4,800 / 120 k triangles; this order: see DESIGN.md section 6).
+    // (warp blocks first: 30.4 / 55.8 us for this kernel in a level of 4,800 / 120 k triangles; this order: see profiles/NOTES.md).
     const unsigned tri_total = gridDim.x - (unsigned)wf.blocks;
     if (blockIdx.x >= tri_total) {
         warp_lds_block_linear(wf.frame, wf.coeffs, wf.warps, width, height, (int)(blockIdx.x - tri_total), (int)threadIdx.x);

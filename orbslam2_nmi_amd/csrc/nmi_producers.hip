@@ -205,7 +205,7 @@ hipError_t launch_level_prep(const float *h_mvps, float *d_mvps, int n_mvps, con
 // matrix arrives through scalar loads instead of 16 LDS reads per view and wavefront.  (The first version culled per
 // 256-point block through LDS with two barriers and kept the matrices in LDS: 73 us for 3 M points x 27 views; this one
 // 62 us = 15 us loading the cloud + 16 us culling + 32 us in the view loop, the atomics being 5 of those -- ablations
-// in DESIGN.md section 7b.)
+// in profiles/NOTES.md.)
 constexpr int kMaxViewsPerLaunch = 64;
 
 template <typename T>

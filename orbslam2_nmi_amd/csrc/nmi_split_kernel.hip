@@ -9,7 +9,7 @@
 // [j * 256/K, (j+1) * 256/K) as 32-bit LDS counters (K = 8: 32 KiB).  Every part streams ALL pixels of the pair (0.6 MB,
 // from the XCD's L2 after the first part touched them: the parts of a candidate are placed on one XCD) but issues the
 // LDS atomic only for pixels whose render intensity falls into its rows.  Each part therefore holds COMPLETE rows:
-//   * no merge of partial histograms (what sank the pixel-split attempt of round 1: device-scope atomics);
+//   * no merge of partial histograms (what sank the pixel-split attempt of round 1: device-scope atomics, profiles/NOTES.md; nmi_pix_kernel.hip is the form that works: one owner, write-through units, masks as flags);
 //   * 32-bit counters: no wrap bookkeeping, BG-off and reduced-bin contexts take the same path;
 //   * the row trees of AddvectorParwiseMidKernel (NMI.cu:270-287) run per row exactly as in nmi_grid_kernel, so the
 //     256 row sums and the render marginal are final when a part stores them.

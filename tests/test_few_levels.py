@@ -60,7 +60,7 @@ def test_posterised_grids_equal_the_oracle(nmi, levels):
 
 
 def test_full_size_posterised_config2(nmi):
-    """640x480, 27 x 27 candidates posterised to 16 and to 4 levels (the two cliff rows of DESIGN.md section 4)."""
+    """640x480, 27 x 27 candidates posterised to 16 and to 4 levels (the two cliff rows of profiles/r03_b/content_sensitivity.txt)."""
     from orbslam2_nmi_amd import synthetic as sy
     wl = sy.workload(640, 480, 27, 27)
     for lv in (16, 4):

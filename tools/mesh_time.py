@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time of nmi_render_mesh (27 views, 848x480) for one textured plane three views wide, at several tessellations: from
-façade-like triangles of ~1,000 pixels to sub-pixel ones.  DESIGN.md section 3 quotes these numbers."""
+façade-like triangles of ~1,000 pixels to sub-pixel ones.  DESIGN.md sections 4 and 6 quote these numbers."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
