@@ -763,6 +763,10 @@ __global__ __launch_bounds__(NMI_BLOCK_THREADS) void NMI_GRID_KERNEL_NAME(GridAr
             table_pending = false;
         }
         NMI_GRID_STAMP(2);  // this wavefront's share of the pixels done
+#ifdef NMI_GRID_KERNEL_STAMPED
+        // ... and every wavefront's, behind the [workgroups][8] block: [workgroups][16]
+        if (a.dbg_stamps && lane == 0 && stamp_on) a.dbg_stamps[gridDim.x * 8 + blockIdx.x * 16 + wave] = wall_clock64();
+#endif
         __syncthreads();  // B1
         NMI_GRID_STAMP(3);
         if (a.phase_mask & 2) decode_phase<kZero0>(lds, par, a, wave, lane);

@@ -19,7 +19,7 @@ names = ["start", "cleared", "hist(wave0)", "B1", "decoded(B2)", "scored", "end"
 with nmi.NmiContext(w, h) as ctx:
     ctx.set_option(ctx.OPT_SPLIT, 0)
     n_wg = min(S * Wn, 256)
-    st = torch.zeros((n_wg, 8), dtype=torch.int64, device="cuda")
+    st = torch.zeros((n_wg * 24,), dtype=torch.int64, device="cuda")   # [n_wg][8] phase stamps, then [n_wg][16]: every wavefront's last pixel
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for rep in range(20):
         ctx.search_grid(rs, ws)
@@ -39,7 +39,9 @@ with nmi.NmiContext(w, h) as ctx:
         ctx.synchronize()
         ms = ctx.last_kernel_ms()
         ctx.set_profiling(False)
-        a = st.cpu().numpy().astype(np.float64)
+        raw = st.cpu().numpy().astype(np.float64)
+        a = raw[: n_wg * 8].reshape(n_wg, 8)
+        wv = raw[n_wg * 8:].reshape(n_wg, 16)
         live = a[:, 1] > 0
         t0 = a[live, 0].min()
         print(f"launch {rep}: {live.sum()} workgroups, stamped kernel {ms * 1e3:.1f} us by HIP events; times from the first workgroup's start")
@@ -48,6 +50,10 @@ with nmi.NmiContext(w, h) as ctx:
             col = col[col > 0]
             if col.size:
                 print(f"  {names[k]:>12}: mean {np.mean(col - t0) / 100:6.2f} us  min {np.min(col - t0) / 100:6.2f}  max {np.max(col - t0) / 100:6.2f}  (n={col.size})")
+        rel = (wv[live] - a[live, 1:2]) / 100   # every wavefront's last pixel, from its workgroup's "cleared" stamp
+        print("  wavefronts' pixel loops end (us after the clear), mean over workgroups: " + " ".join(f"{x:.1f}" for x in rel.mean(axis=0)))
+        srt = np.sort(rel, axis=1)
+        print("  ... sorted within each workgroup (1st ... 16th to finish):            " + " ".join(f"{x:.1f}" for x in srt.mean(axis=0)))
         per = (a[live, 1:7] - a[live, 0:6]) / 100
         print("  per-workgroup phase lengths (mean): " + "  ".join(f"{names[k + 1]} {per[:, k].mean():.2f}" for k in range(6)))
     ctx.set_option(ctx.OPT_STAMPS, 0)
