@@ -625,6 +625,10 @@ class NmiStream:
             self.ctx._check(self._lib.nmi_stream_submit(self._h, rs.data_ptr(), rs.shape[0], fp, mp, wn, C.byref(t)),
                             "nmi_stream_submit")
         else:
+            if block is None:
+                # a communicator without a block: a blockless level cannot say how many warps a frame-less submission reuses
+                raise ValueError("NmiStream.submit(comm=...) needs block=(s_offset, S_total, w_offset, Wn_total): the position of this "
+                                 "rank's views and warps in the level the ranks all-reduce over")
             so, st, wo, wt = (int(v) for v in block)
             self.ctx._check(self._lib.nmi_stream_submit_block(self._h, rs.data_ptr() if rs.shape[0] else None, rs.shape[0], so, st, fp, mp,
                                                               wn, wo, wt, comm, C.byref(t)), "nmi_stream_submit_block")

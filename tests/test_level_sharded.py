@@ -151,5 +151,7 @@ def test_stream_blocks_compose_to_the_level(nmi):
                     assert (idx, score) == ((4 + wi) * S + so + si, blk.max())
                     t = st.submit(hr[:0], block=(S, S, 4, Wn), comm=comm)                          # empty block: only the exchange
                     assert st.wait(t) == (-1, np.float32(0))
+                with pytest.raises(ValueError):                                                   # a communicator needs the block's position
+                    st.submit(hr, hf, Ms, comm=comm)
         finally:
             capi.rccl_comm_destroy(comm)
