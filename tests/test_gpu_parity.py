@@ -415,6 +415,32 @@ def test_grid_config4_shard_shape(nmi):
     assert nmi.key_unpack(key) == (w * s_total + 64 * rank + s, bo)
 
 
+def test_grid_config4_whole_grid_and_its_eight_shards(nmi):
+    """BASELINE.json configs[3] at full size on one GPU: 848x480, 512 renders x 64 warps = 32,768 candidates.  The whole rating
+    table == the oracle's; then the grid as the 8 ranks of that config would score it (64 renders each, global indices): every
+    shard's table is its slice, and the MAX of the 8 packed keys is the whole grid's winner (what the RCCL all-reduce computes)."""
+    from oracle import binding as oc
+    from orbslam2_nmi_amd import sharding, synthetic as sy
+    wl = sy.workload(848, 480, 512, 64, seed=21)
+    rs, ws = wl["render_stack"], wl["warp_stack"]
+    with oc.rounded():
+        ro, io, bo = oc.search_grid(rs, ws, threads=16)
+    d_rs, d_ws = dev(rs), dev(ws)
+    with nmi.NmiContext(848, 480) as ctx:
+        t = torch.zeros(64, 512, device="cuda")
+        assert ctx.search_grid(d_rs, d_ws, t) == (io, bo)
+        assert (t.cpu().numpy().view(np.uint32) == ro.view(np.uint32)).all()
+        assert io == wl["planted"]
+        keys = []
+        for rank in range(8):
+            so, sc, wo, wc = sharding.grid_shard(512, 64, rank, 8)
+            assert (so, sc, wo, wc) == (64 * rank, 64, 0, 64)
+            ts = torch.zeros(64, 64, device="cuda")
+            keys.append(ctx.search_grid_shard(d_rs[so:so + sc], so, 512, d_ws, ts))
+            assert (ts.cpu().numpy().view(np.uint32) == ro[:, so:so + sc].view(np.uint32)).all(), rank
+        assert nmi.key_unpack(max(keys)) == (io, bo)
+
+
 def test_full_size_properties_without_oracle(nmi, split_mode):
     """Size-independent properties at full size (no oracle): permutation invariance of the histogram under a common
     pixel permutation, symmetry of SUC in its two images, identical pair -> 1, and arg-max consistency."""
