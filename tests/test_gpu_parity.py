@@ -989,6 +989,11 @@ def test_fuzz_campaign_against_the_oracle(nmi):
     # rest back to the general kernel on the device
     C = nmi.NmiContext
     assert fuzz_parity.run(120, seed=12, verbose=False, options={C.OPT_SPLIT: 0, C.OPT_CONTENT_PATH: 1}, kinds=7) == 0.0
+    # pixel ranges only (nmi_pix_kernel) for every grid they fit: 3 ranges with the owner's share at its default, 5 with equal
+    # shares, 2 with a large bias; grids up to 12 x 12 (mid-size ones among them), ragged widths, every content kind
+    for ranges, bias, seed in ((3, 49152, 13), (5, 0, 14), (2, 200000, 15)):
+        assert fuzz_parity.run(60, seed=seed, verbose=False, kinds=7, max_side=12,
+                               options={C.OPT_SPLIT: 1, C.OPT_SPLIT_PIXELS: ranges, C.OPT_PIX_OWNER_BIAS: bias, C.OPT_CONTENT_PATH: 0}) == 0.0
 
 
 def test_two_contexts_from_two_threads(nmi):
