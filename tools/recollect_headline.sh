@@ -1,4 +1,6 @@
 set -o pipefail
+# Re-takes the headline profile (bench line, rocprofv3 --kernel-trace --stats, the three --pmc passes, grid stamps) into gpurun_out/r04_final
+# after a late change of the kernel sources, so that bench.py's static stamps (roofline.static) are fresh.  On the GPU box, repo root.
 cd /root/repo
 OUT=$PWD/gpurun_out/r04_final
 ROOT=$PWD
