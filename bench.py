@@ -829,7 +829,8 @@ def main():
             "warmup": args.warmup,
             "clock_warmup_ms": args.clock_warmup_ms,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "step_mode": "blocking call per step" if blocking_mode else
+            "step_mode": ("blocking call per step" + (": nmi_search_grid through NmiContext.bind_search (arguments converted to C once), winner checked every step"
+                                                       if dist is None else "")) if blocking_mode else
                          "steps enqueued back to back; every step's winner read back and checked inside the timed region",
             "blocking_call_ms": blocking_call_ms,
             "streams": n_streams,
