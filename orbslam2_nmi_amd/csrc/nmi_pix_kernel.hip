@@ -30,7 +30,6 @@
 //     replayed from a captured graph with frozen arguments (bumped by the graph's first node), absent otherwise.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #define NMI_KERNELS_DEVICE_ONLY 1
 #include "nmi_kernels.hip"  // Lds, histogram_phase, decode_phase, final_phase, finish_search, exact_candidate
@@ -534,7 +533,7 @@ hipError_t launch_pix(const GridArgs &a, int pix_parts, double owner_share, bool
             o = o < 1 ? 1 : o;
             if (o + (pix_parts - 1) * b > 48) break;
             const double err = fabs((double)o / (o + (pix_parts - 1) * b) - f);
-            static const double kCloser = getenv("NMI_PIX_CLOSER") ? atof(getenv("NMI_PIX_CLOSER")) : 0.03;  // (experiments)
+            constexpr double kCloser = 0.03;
             if (err < best - kCloser) best = err, own = o, hlp = b;  // a longer period has to be clearly closer: dealt in runs of 5 pieces
                                                                       // (8 rows) one helper was 16 % slower than the other on the benchmark's frames
         }
