@@ -1,6 +1,7 @@
 """Long randomised parity campaign (tests/fuzz_parity.py) over the kernel selections: default, few-levels first, low few-levels
-limit, general kernel only; small and larger grids.  On a GPU box:  python tools/long_fuzz.py"""
+limit, general kernel only; small and larger grids.  On a GPU box:  python tools/long_fuzz.py [seed offset]"""
 import sys, time
+OFFSET = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import fuzz_parity
 import orbslam2_nmi_amd as nmi
@@ -15,5 +16,5 @@ for name, n, seed, opts, kinds, side in (("default options", 1200, 101, None, 7,
                                    ("pixel ranges only, 3 per candidate, grids up to 16 x 16", 400, 107, {C.OPT_SPLIT: 1, C.OPT_SPLIT_PIXELS: 3, C.OPT_CONTENT_PATH: 0}, 7, 16),
                                    ("pixel ranges only, 2 per candidate, owner bias 150 k", 300, 108, {C.OPT_SPLIT: 1, C.OPT_SPLIT_PIXELS: 2, C.OPT_PIX_OWNER_BIAS: 150000, C.OPT_CONTENT_PATH: 0}, 7, 11),
                                    ("pixel ranges only, 5 per candidate, equal shares", 300, 109, {C.OPT_SPLIT: 1, C.OPT_SPLIT_PIXELS: 5, C.OPT_PIX_OWNER_BIAS: 0, C.OPT_CONTENT_PATH: 0}, 7, 7)):
-    w = fuzz_parity.run(n, seed=seed, verbose=False, options=opts, kinds=kinds, max_side=side)
-    print(f"{name}: {n} cases, worst |score error| {w:.1e}, {time.time() - t0:.0f} s", flush=True)
+    w = fuzz_parity.run(n, seed=seed + OFFSET, verbose=False, options=opts, kinds=kinds, max_side=side)
+    print(f"{name} (seed {seed + OFFSET}): {n} cases, worst |score error| {w:.1e}, {time.time() - t0:.0f} s", flush=True)
