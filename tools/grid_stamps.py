@@ -10,11 +10,17 @@ import torch
 import orbslam2_nmi_amd as nmi
 from orbslam2_nmi_amd import synthetic as sy
 
+NOISE = "--noise" in sys.argv   # uniform noise instead of the benchmark's frames: no flat regions, no two lanes on one bin
+sys.argv = [x for x in sys.argv if x != "--noise"]
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 9
 Wn = int(sys.argv[2]) if len(sys.argv) > 2 else 9
 w, h = 640, 480
 wl = sy.workload(w, h, 27, 27, seed=1234)
 rs, ws = torch.from_numpy(wl["render_stack"]).cuda()[:S].contiguous(), torch.from_numpy(wl["warp_stack"]).cuda()[:Wn].contiguous()
+if NOISE:
+    g = torch.Generator(device="cuda").manual_seed(1)
+    rs = torch.randint(0, 256, rs.shape, dtype=torch.uint8, device="cuda", generator=g)
+    ws = torch.randint(0, 256, ws.shape, dtype=torch.uint8, device="cuda", generator=g)
 names = ["start", "cleared", "hist(wave0)", "B1", "decoded(B2)", "scored", "end"]
 with nmi.NmiContext(w, h) as ctx:
     ctx.set_option(ctx.OPT_SPLIT, 0)
